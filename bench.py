@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- the hashes.yaml SHA-512 pass on MI355X, BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A step is one pass of the hot path over one batch of synthetic input: every
+file of the tree(s) hashed by the HIP kernels from bytes already resident in
+HBM (snaphash_sha512_device), plus -- for N > 1 -- the RCCL all-gather of the
+digest vector.  Workload at N = 1: BASELINE config 2, the 10 000 x 1 MiB tree
+plus its 1 MiB archive stand-in (10 001 streams, 10 001 MiB).  At N > 1 the
+default is weak scaling: N such trees form one file list that is LPT-sharded
+over the ranks (per-GPU work fixed); --scaling strong shards ONE tree instead
+(BASELINE config 4 literally; stream-count-bound).
+
+Prints ONE JSON line on rank 0.  `value` is whole-job GiB/s with inputs resident
+in HBM; `roofline` is the dominant kernel against the 8 TB/s HBM-read roofline
+(algorithmic bytes = file bytes hashed); `cpu_baseline` is the oracle (the C
+restatement of the reference's serial path) timed on this box's host cores on
+a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "pair"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sizes, budget_s):
+    """The oracle (C restatement of helpers.Sha512sum's serial loop) on host cores:
+    files of the same workload, in order, until ~budget_s of CPU work."""
+    from oracle import oracle
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(sizes)
+    done_bytes, files, t_hash = 0, 0, 0.0
+    i = 0
+    while t_hash < budget_s:
+        data = oracle.fill_synthetic(int(sizes[i % n]), i % n)  # generation is not timed
+        off = np.zeros(1, dtype=np.uint64)
+        ln = np.array([len(data)], dtype=np.uint64)
+        t0 = time.perf_counter()
+        oracle.sha512_batch(data, off, ln)
+        t_hash += time.perf_counter() - t0
+        done_bytes += len(data)
+        files += 1
+        i += 1
+    one = done_bytes / t_hash / 2**30
+    # same port on every host core (ctypes releases the GIL): what an
+    # embarrassingly parallel rewrite of the reference's loop would reach
+    cores = os.cpu_count() or 1
+    per = max(4, int(files / t_hash * min(4.0, budget_s)))  # ~4 s of work per core
+    blobs = [oracle.fill_synthetic(int(sizes[k % n]), k % n) for k in range(min(cores, 64))]
+
+    def work(k):
+        b = blobs[k % len(blobs)]
+        off = np.zeros(1, dtype=np.uint64)
+        ln = np.array([len(b)], dtype=np.uint64)
+        for _ in range(per):
+            oracle.sha512_batch(b, off, ln)
+        return per * len(b)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        tot = sum(ex.map(work, range(cores)))
+    allc = tot / (time.perf_counter() - t0) / 2**30
+    return {"value": round(one, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
+            "sample": "first %d files of the workload (%.1f MiB), serial one-file-at-a-time like the reference's "
+                      "filepath.Walk loop, %.1f s of CPU work; content generation not timed" % (files, done_bytes / 2**20, t_hash),
+            "host_cores": cores,
+            "all_cores": {"value": round(allc, 3), "cores": cores,
+                          "note": "same C port on every host core (the reference itself is single-goroutine)"}}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from snappy_amd import Context, _lib, synthetic
+    from snappy_amd.sharded import ShardPlan, gather_digests
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- the job: file list, shard plan (identical on every rank) ------------------
+    tree = synthetic.config_sizes(args.workload)
+    ntrees = world if args.scaling == "weak" else 1
+    sizes = np.tile(tree, ntrees)
+    findex = np.arange(len(sizes), dtype=np.uint64)
+    plan = ShardPlan(sizes, world)
+    mine = plan.members(rank)
+    kmax = plan.kmax
+    my_lens = np.ascontiguousarray(sizes[mine])
+    my_off, my_total = synthetic.pack_offsets(my_lens)
+    my_bytes = int(my_lens.sum())
+    total_bytes = int(sizes.sum())
+
+    kern = {"auto": _lib.KERNEL_AUTO, "wide": _lib.KERNEL_WIDE, "pair": _lib.KERNEL_PAIR}[args.kernel]
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = Context(device=local_rank, kernel=kern, stream=stream)
+    data = torch.empty(max(my_total, 16), dtype=torch.uint8, device="cuda")
+    ctx.fill_synthetic_device(data.data_ptr(), my_off, my_lens, np.ascontiguousarray(findex[mine]))
+    local = torch.zeros((kmax, 64), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+
+    kernel_ms = []
+
+    def step(record):
+        ctx.sha512_device(data.data_ptr(), my_off, my_lens, local.data_ptr())
+        full = gather_digests(local, plan)  # RCCL all-gather of the digest slabs (no-op at N = 1)
+        ctx.sync()
+        if record:
+            kernel_ms.append(ctx.stats()["kernel_ms"])
+        return full
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    full = None
+    for _ in range(args.steps):
+        full = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity spot check, outside the timed region ---------------------------------
+    digests = full.cpu().numpy()
+    parity = None
+    if rank == 0:
+        import hashlib
+        rng = np.random.default_rng(1)
+        sample = sorted(set([0, len(sizes) - 1] + [int(x) for x in rng.integers(0, len(sizes), size=14)]))
+        for i in sample:  # independent check: numpy generator + hashlib (OpenSSL), not the timed path
+            want = hashlib.sha512(synthetic.file_bytes(int(sizes[i]), int(i))).digest()
+            if digests[i].tobytes() != want:
+                raise SystemExit("PARITY FAILURE: file %d digest differs from hashlib.sha512" % i)
+        parity = {"checked_files": len(sample), "result": "bit-exact vs hashlib.sha512",
+                  "sha512_of_digest_vector": hashlib.sha512(digests.tobytes()).hexdigest()[:32]}
+
+    if rank == 0:
+        st = ctx.stats()
+        ms_step = elapsed / args.steps * 1e3
+        value = total_bytes / 2**30 / (elapsed / args.steps)
+        k_ms = float(np.mean(kernel_ms))
+        achieved = my_bytes / (k_ms * 1e-3) / 1e9
+        kname = "sha512_pair_kernel" if st["kernel_used"] == _lib.KERNEL_PAIR else "sha512_wide_kernel"
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % kname)
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "GiB/s hashed (whole node), bit-exact hashes.yaml, 10k x 1 MiB tree",
+            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s: %d tree(s) of %d files (%d x %d B + archive stand-in), HBM-resident, "
+                                   "LPT-sharded over %d GPU(s)%s" % (
+                                       args.workload, ntrees, len(tree), len(tree) - 1, int(tree[0]), world,
+                                       ", RCCL all-gather of the digest vector" if world > 1 else ""),
+                       "files": int(len(sizes)), "bytes": total_bytes, "kernel": kname,
+                       "sha512_blocks_per_step": int(st["blocks"]) * 1 if world == 1 else None},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "kernel": kname, "kernel_ms": round(k_ms, 4), "bytes_per_launch": my_bytes,
+                         "note": "algorithmic bytes = file bytes hashed by rank 0's launch; SHA-512 is integer-VALU "
+                                 "and stream-count bound, not HBM bound (DESIGN.md)"},
+            "parity": parity,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(tree, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+/*
+ * snaphash.h -- C ABI of libsnaphash.so: the MI355X (gfx950) implementation of
+ * snappy's per-file SHA-512 integrity pass (hashes.yaml).
+ *
+ * The reference (wolfbox/snappy 1.0.1, Go) has no FFI for this path; its seam
+ * is two Go functions.  Each entry point below names the reference interface it
+ * replaces (paths relative to the upstream tree):
+ *
+ *   helpers/helpers.go:187-201   func Sha512sum(infile string) (string, error)
+ *   snappy/build.go:216-270      func writeHashes(buildDir, dataTar string) error
+ *   snappy/hashes.go:25-110      yamlFileMode / fileHash / hashesYaml (format)
+ *   snappy/click.go:330-338,970  writeHashesFile (install side: where Verify hooks in)
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ or torch types cross the line.
+ *   - Return 0 on success, a negative SNAPHASH_E* code otherwise.  As in the
+ *     reference (build.go:242-244) the first per-file error fails the whole
+ *     batch and no output may be trusted.
+ *   - Hashing runs on the GPU only.  There is no CPU fallback: without a usable
+ *     gfx950 device snaphash_init fails with SNAPHASH_EDEVICE.
+ *   - The caller owns every input and output buffer; the library keeps no caller
+ *     pointer past return.  Only snaphash_tree's yaml_out and snaphash_walk's
+ *     record set are library-allocated (snaphash_free / snaphash_records_free).
+ *   - A ctx is bound to one device and is not thread-safe (one call in flight per
+ *     ctx); distinct ctxs may be used concurrently.  No signal handlers are
+ *     installed (the Go runtime owns them).
+ *   - Digests are raw 64-byte big-endian SHA-512 values; the Go wrapper
+ *     hex-encodes them with encoding/hex (lowercase, helpers.go:200).
+ */
+#ifndef SNAPHASH_H
+#define SNAPHASH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNAPHASH_ABI_VERSION 1
+
+enum {
+    SNAPHASH_OK = 0,
+    SNAPHASH_EINVAL = -1,   /* bad argument (NULL, misaligned device offset, ...) */
+    SNAPHASH_ENOMEM = -2,   /* host or device allocation failed */
+    SNAPHASH_EIO = -3,      /* open/read/lstat failed; errno in per-file status / last_error */
+    SNAPHASH_EDEVICE = -4,  /* no gfx950 device, HIP error, kernel failure */
+    SNAPHASH_EMODE = -5,    /* "Unknown file mode" (hashes.go:47): device, fifo, socket */
+    SNAPHASH_ENAME = -6,    /* file name outside the plain-scalar set the YAML emitter reproduces */
+    SNAPHASH_EPARSE = -7,   /* hashes.yaml text not understood */
+    SNAPHASH_EMISMATCH = -8 /* snaphash_verify: tree differs from hashes.yaml */
+};
+
+enum { /* snaphash_config.kernel */
+    SNAPHASH_KERNEL_AUTO = 0, /* pick from the stream count */
+    SNAPHASH_KERNEL_WIDE = 1, /* one lane per file stream (many-stream regime) */
+    SNAPHASH_KERNEL_PAIR = 2  /* lane pair + schedule-helper wave per stream (stream-starved regime) */
+};
+
+typedef struct snaphash_ctx snaphash_ctx;
+
+typedef struct snaphash_config {
+    uint32_t struct_size;   /* sizeof(snaphash_config) */
+    int32_t device;         /* HIP device ordinal; -1 = the calling thread's current device */
+    uint64_t staging_bytes; /* size of EACH of the two pinned-host/HBM staging buffers; 0 = 256 MiB */
+    uint32_t kernel;        /* SNAPHASH_KERNEL_* */
+    uint32_t reserved;
+    void *stream;           /* hipStream_t to launch on; NULL = a stream owned by the ctx */
+} snaphash_config;
+
+typedef struct snaphash_stats { /* of the most recent hashing call on the ctx */
+    uint64_t bytes_hashed;  /* sum of file/buffer lengths */
+    uint64_t blocks;        /* SHA-512 compression-function calls (incl. padding blocks) */
+    uint64_t streams;       /* files/buffers hashed */
+    uint32_t launches;      /* kernel launches issued */
+    uint32_t kernel_used;   /* SNAPHASH_KERNEL_WIDE or _PAIR */
+    double kernel_ms;       /* sum over launches, HIP events on the launch stream */
+    double h2d_ms;          /* host->HBM copies (files/buffers entry points) */
+    double wall_ms;         /* whole call, host clock */
+} snaphash_stats;
+
+/* ---- lifetime -------------------------------------------------------------- */
+int snaphash_init(const snaphash_config *cfg /* may be NULL */, snaphash_ctx **out);
+void snaphash_destroy(snaphash_ctx *ctx);
+int snaphash_abi_version(void);
+
+/* ---- the primitive: helpers.Sha512sum, batched ----------------------------- */
+
+/* Replaces n calls of helpers.Sha512sum(path) (helpers.go:188).  The library
+ * opens and reads the files itself (pread into pinned staging, double-buffered
+ * H2D, chunked for files larger than the staging buffer).  digests: n*64 bytes.
+ * status (may be NULL): per file 0 or the errno of the failed open/read. */
+int snaphash_sha512_files(snaphash_ctx *ctx, const char *const *paths, size_t n,
+                          uint8_t *digests, int32_t *status);
+
+/* Same, for content already in host memory (what io.Copy would have streamed). */
+int snaphash_sha512_buffers(snaphash_ctx *ctx, const void *const *bufs, const uint64_t *lens,
+                            size_t n, uint8_t *digests);
+
+/* Same, for content already resident in HBM: file i is the byte range
+ * [d_base+offsets[i], +lens[i]).  offsets/lens are host arrays; every offset and
+ * d_base must be 16-byte aligned.  d_digests is device memory, n*64 bytes.
+ * Enqueues on the ctx stream and returns; snaphash_sync waits for completion.
+ * This is the kernel-resident (roofline) entry point. */
+int snaphash_sha512_device(snaphash_ctx *ctx, const void *d_base, const uint64_t *offsets,
+                           const uint64_t *lens, size_t n, void *d_digests);
+int snaphash_sync(snaphash_ctx *ctx);
+
+/* ---- the pass: writeHashes / getHashes / Verify ----------------------------- */
+
+/* writeHashes (build.go:216-270) minus the file write (north_star "getHashes"):
+ * archive digest of data_tar + walk + per-file digests + yaml.v2-compatible text.
+ * *yaml_out is malloc'd; release with snaphash_free. */
+int snaphash_tree(snaphash_ctx *ctx, const char *build_dir, const char *data_tar,
+                  char **yaml_out, size_t *yaml_len);
+
+/* writeHashes itself: also MkdirAll(build_dir/DEBIAN, 0755) and writes
+ * DEBIAN/hashes.yaml with mode 0644 (build.go:218-219, :269). */
+int snaphash_write_hashes(snaphash_ctx *ctx, const char *build_dir, const char *data_tar);
+
+typedef struct snaphash_mismatch {
+    int32_t kind;     /* 1 missing on disk, 2 not in yaml, 3 size, 4 sha512, 5 mode, 6 archive-sha512 */
+    int32_t reserved;
+    char name[4096];  /* tree-relative name of the first offending record */
+} snaphash_mismatch;
+
+/* Inverse of writeHashes (absent upstream; hook point click.go:970): parse
+ * yaml, re-walk inst_dir with the same rules, re-hash every regular file on the
+ * GPU and compare name set, size, digest and mode.  data_tar may be NULL (the
+ * archive digest is then not checked).  Returns 0, SNAPHASH_EMISMATCH (first
+ * mismatch in *first, may be NULL) or another error. */
+int snaphash_verify(snaphash_ctx *ctx, const char *inst_dir, const char *data_tar,
+                    const char *yaml, size_t yaml_len, snaphash_mismatch *first);
+
+void snaphash_free(void *p);
+
+/* ---- host-side pieces of the pass (no device needed) ----------------------- */
+
+typedef struct snaphash_records snaphash_records;
+typedef struct snaphash_record {
+    const char *name;  /* relative to the walk root, '/' separated; owned by the record set */
+    uint32_t st_mode;  /* lstat st_mode */
+    int32_t is_regular;
+    int64_t size;      /* valid when is_regular */
+    const char *path;  /* root-joined path; owned by the record set */
+} snaphash_record;
+
+/* filepath.Walk exactly as writeHashes uses it (build.go:228-259): pre-order,
+ * children byte-wise sorted per directory, lstat, "/DEBIAN" string-prefix skip,
+ * root skipped. */
+int snaphash_walk(const char *build_dir, snaphash_records **out);
+size_t snaphash_records_count(const snaphash_records *r);
+int snaphash_records_get(const snaphash_records *r, size_t i, snaphash_record *out);
+void snaphash_records_free(snaphash_records *r);
+
+/* yaml.Marshal(hashesYaml) for the records (hashes.go:93-110).  file_digests
+ * holds one raw 64-byte digest per REGULAR record, in record order. */
+int snaphash_emit_yaml(const snaphash_records *r, const uint8_t archive_digest[64],
+                       const uint8_t *file_digests, char **yaml_out, size_t *yaml_len);
+
+/* yamlFileMode.MarshalYAML / UnmarshalYAML (hashes.go:33-88).  out: 11 bytes.
+ * mode_parse yields a POSIX st_mode (S_IFDIR/S_IFLNK/S_IFREG | perm bits) and
+ * rejects the empty string instead of indexing it. */
+int snaphash_mode_string(uint32_t st_mode, char out[11]);
+int snaphash_mode_parse(const char *s, uint32_t *st_mode);
+
+/* Longest-processing-time shard assignment of n files (by SHA-512 block count)
+ * to nshards GPUs; shard_of[i] in [0,nshards).  Deterministic. */
+int snaphash_lpt_assign(const uint64_t *lens, size_t n, int nshards, int32_t *shard_of);
+
+/* Deterministic synthetic content (SURVEY sec. 8d generator), written straight
+ * into HBM; offsets/lens/file_index are host arrays.  Benchmark/test utility. */
+int snaphash_fill_synthetic_device(snaphash_ctx *ctx, void *d_base, const uint64_t *offsets,
+                                   const uint64_t *lens, const uint64_t *file_index, size_t n);
+
+/* ---- diagnostics ------------------------------------------------------------ */
+const char *snaphash_strerror(int code);
+const char *snaphash_last_error(const snaphash_ctx *ctx);
+void snaphash_get_stats(const snaphash_ctx *ctx, snaphash_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNAPHASH_H */

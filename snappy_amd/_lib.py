@@ -1,0 +1,266 @@
+"""ctypes binding of libsnaphash.so (include/snaphash.h).
+
+The library is the product: HIP kernels for gfx950 behind a C ABI.  There is
+no Python or CPU fallback -- if the shared object is missing this module
+raises at import of the symbol table, and if no MI355X is visible
+``Context()`` raises ``SnaphashError(EDEVICE)``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnaphash.so")
+
+OK, EINVAL, ENOMEM, EIO, EDEVICE, EMODE, ENAME, EPARSE, EMISMATCH = 0, -1, -2, -3, -4, -5, -6, -7, -8
+KERNEL_AUTO, KERNEL_WIDE, KERNEL_PAIR = 0, 1, 2
+
+# every symbol include/snaphash.h declares
+EXPORTS = [
+    "snaphash_init", "snaphash_destroy", "snaphash_abi_version",
+    "snaphash_sha512_files", "snaphash_sha512_buffers", "snaphash_sha512_device", "snaphash_sync",
+    "snaphash_tree", "snaphash_write_hashes", "snaphash_verify", "snaphash_free",
+    "snaphash_walk", "snaphash_records_count", "snaphash_records_get", "snaphash_records_free",
+    "snaphash_emit_yaml", "snaphash_mode_string", "snaphash_mode_parse", "snaphash_lpt_assign",
+    "snaphash_fill_synthetic_device", "snaphash_strerror", "snaphash_last_error", "snaphash_get_stats",
+]
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("staging_bytes", ctypes.c_uint64),
+                ("kernel", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("stream", ctypes.c_void_p)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("bytes_hashed", ctypes.c_uint64), ("blocks", ctypes.c_uint64), ("streams", ctypes.c_uint64),
+                ("launches", ctypes.c_uint32), ("kernel_used", ctypes.c_uint32), ("kernel_ms", ctypes.c_double),
+                ("h2d_ms", ctypes.c_double), ("wall_ms", ctypes.c_double)]
+
+
+class Mismatch(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("name", ctypes.c_char * 4096)]
+
+
+class Record(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("st_mode", ctypes.c_uint32), ("is_regular", ctypes.c_int32),
+                ("size", ctypes.c_int64), ("path", ctypes.c_char_p)]
+
+
+class SnaphashError(Exception):
+    def __init__(self, code, message=""):
+        self.code = code
+        super().__init__("snaphash error %d (%s)%s" % (code, strerror(code), (": " + message) if message else ""))
+
+
+_lib = None
+
+
+def lib():
+    """Load libsnaphash.so; raises OSError loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("%s not found: build it with `make -C snappy_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, u64p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)
+    L.snaphash_init.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
+    L.snaphash_destroy.argtypes = [vp]
+    L.snaphash_destroy.restype = None
+    L.snaphash_abi_version.argtypes = []
+    L.snaphash_sha512_files.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), sz, vp, ctypes.POINTER(ctypes.c_int32)]
+    L.snaphash_sha512_buffers.argtypes = [vp, ctypes.POINTER(vp), u64p, sz, vp]
+    L.snaphash_sha512_device.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.snaphash_sync.argtypes = [vp]
+    L.snaphash_tree.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.snaphash_write_hashes.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+    L.snaphash_verify.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, sz, ctypes.POINTER(Mismatch)]
+    L.snaphash_free.argtypes = [vp]
+    L.snaphash_free.restype = None
+    L.snaphash_walk.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.snaphash_records_count.argtypes = [vp]
+    L.snaphash_records_count.restype = sz
+    L.snaphash_records_get.argtypes = [vp, sz, ctypes.POINTER(Record)]
+    L.snaphash_records_free.argtypes = [vp]
+    L.snaphash_records_free.restype = None
+    L.snaphash_emit_yaml.argtypes = [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.snaphash_mode_string.argtypes = [ctypes.c_uint32, ctypes.c_char_p]
+    L.snaphash_mode_parse.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)]
+    L.snaphash_lpt_assign.argtypes = [vp, sz, ctypes.c_int, vp]
+    L.snaphash_fill_synthetic_device.argtypes = [vp, vp, vp, vp, vp, sz]
+    L.snaphash_strerror.argtypes = [ctypes.c_int]
+    L.snaphash_strerror.restype = ctypes.c_char_p
+    L.snaphash_last_error.argtypes = [vp]
+    L.snaphash_last_error.restype = ctypes.c_char_p
+    L.snaphash_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.snaphash_get_stats.restype = None
+    _lib = L
+    return L
+
+
+def strerror(code):
+    try:
+        return lib().snaphash_strerror(code).decode()
+    except OSError:
+        return "?"
+
+
+class Context:
+    """One snaphash_ctx: bound to one GPU, one call in flight at a time."""
+
+    def __init__(self, device=-1, staging_bytes=0, kernel=KERNEL_AUTO, stream=None):
+        cfg = Config(ctypes.sizeof(Config), device, staging_bytes, kernel, 0, stream)
+        h = ctypes.c_void_p()
+        rc = lib().snaphash_init(ctypes.byref(cfg), ctypes.byref(h))
+        if rc:
+            raise SnaphashError(rc, "snaphash_init (is an MI355X/gfx950 visible?)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().snaphash_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc:
+            raise SnaphashError(rc, lib().snaphash_last_error(self._h).decode(errors="replace"))
+
+    # ---- primitive -----------------------------------------------------------------
+    def sha512_files(self, paths):
+        """-> list of 64-byte digests; raises OSError(errno) for the first unreadable file."""
+        n = len(paths)
+        arr = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(p) for p in paths])
+        out = ctypes.create_string_buffer(64 * max(n, 1))
+        status = (ctypes.c_int32 * max(n, 1))()
+        rc = lib().snaphash_sha512_files(self._h, arr, n, out, status)
+        if rc == EIO:
+            for i in range(n):
+                if status[i]:
+                    raise OSError(status[i], os.strerror(status[i]), os.fsdecode(paths[i]))
+        self._check(rc)
+        return [out.raw[64 * i:64 * i + 64] for i in range(n)]
+
+    def sha512_buffers(self, bufs):
+        n = len(bufs)
+        keep = [bytes(b) if not isinstance(b, (bytes, bytearray)) else b for b in bufs]
+        cbufs = [(ctypes.c_char * max(len(b), 1)).from_buffer_copy(b if len(b) else b"\0") for b in keep]
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[ctypes.addressof(c) for c in cbufs])
+        lens = (ctypes.c_uint64 * max(n, 1))(*[len(b) for b in keep])
+        out = ctypes.create_string_buffer(64 * max(n, 1))
+        self._check(lib().snaphash_sha512_buffers(self._h, ptrs, lens, n, out))
+        return [out.raw[64 * i:64 * i + 64] for i in range(n)]
+
+    def sha512_device(self, d_base, offsets, lens, d_digests):
+        """HBM-resident batch.  d_base / d_digests: device addresses (int);
+        offsets / lens: contiguous numpy uint64 arrays.  Asynchronous: call sync()."""
+        n = len(offsets)
+        self._check(lib().snaphash_sha512_device(self._h, d_base, offsets.ctypes.data, lens.ctypes.data, n, d_digests))
+
+    def sync(self):
+        self._check(lib().snaphash_sync(self._h))
+
+    def fill_synthetic_device(self, d_base, offsets, lens, file_index):
+        self._check(lib().snaphash_fill_synthetic_device(self._h, d_base, offsets.ctypes.data, lens.ctypes.data,
+                                                         file_index.ctypes.data, len(offsets)))
+
+    # ---- pass ------------------------------------------------------------------------
+    def tree(self, build_dir, data_tar):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(lib().snaphash_tree(self._h, os.fsencode(build_dir), os.fsencode(data_tar), ctypes.byref(p),
+                                        ctypes.byref(n)))
+        try:
+            return ctypes.string_at(p.value, n.value)
+        finally:
+            lib().snaphash_free(p)
+
+    def write_hashes(self, build_dir, data_tar):
+        self._check(lib().snaphash_write_hashes(self._h, os.fsencode(build_dir), os.fsencode(data_tar)))
+
+    def verify(self, inst_dir, yaml_bytes, data_tar=None):
+        """-> None when the tree matches, else (kind, name) of the first mismatch."""
+        m = Mismatch()
+        rc = lib().snaphash_verify(self._h, os.fsencode(inst_dir), os.fsencode(data_tar) if data_tar else None,
+                                   yaml_bytes, len(yaml_bytes), ctypes.byref(m))
+        if rc == EMISMATCH:
+            return (m.kind, m.name.decode(errors="replace"))
+        self._check(rc)
+        return None
+
+    def stats(self):
+        s = Stats()
+        lib().snaphash_get_stats(self._h, ctypes.byref(s))
+        return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+
+# ---- host-only entry points (no device) ----------------------------------------------
+
+def walk(build_dir):
+    """filepath.Walk as writeHashes drives it -> list of dicts in walk order."""
+    h = ctypes.c_void_p()
+    rc = lib().snaphash_walk(os.fsencode(build_dir), ctypes.byref(h))
+    if rc:
+        raise SnaphashError(rc, build_dir)
+    try:
+        out = []
+        r = Record()
+        for i in range(lib().snaphash_records_count(h)):
+            lib().snaphash_records_get(h, i, ctypes.byref(r))
+            out.append({"name": r.name.decode(errors="surrogateescape"), "st_mode": r.st_mode,
+                        "is_regular": bool(r.is_regular), "size": r.size,
+                        "path": r.path.decode(errors="surrogateescape")})
+        return out
+    finally:
+        lib().snaphash_records_free(h)
+
+
+def emit_yaml(build_dir, archive_digest, file_digests):
+    """yaml.Marshal(hashesYaml) for the tree at build_dir with the given raw digests."""
+    h = ctypes.c_void_p()
+    rc = lib().snaphash_walk(os.fsencode(build_dir), ctypes.byref(h))
+    if rc:
+        raise SnaphashError(rc, build_dir)
+    try:
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        blob = b"".join(file_digests)
+        rc = lib().snaphash_emit_yaml(h, archive_digest, blob if blob else None, ctypes.byref(p), ctypes.byref(n))
+        if rc:
+            raise SnaphashError(rc)
+        try:
+            return ctypes.string_at(p.value, n.value)
+        finally:
+            lib().snaphash_free(p)
+    finally:
+        lib().snaphash_records_free(h)
+
+
+def mode_string(st_mode):
+    buf = ctypes.create_string_buffer(11)
+    rc = lib().snaphash_mode_string(st_mode, buf)
+    if rc:
+        raise SnaphashError(rc)
+    return buf.value.decode()
+
+
+def mode_parse(s):
+    m = ctypes.c_uint32()
+    rc = lib().snaphash_mode_parse(s.encode(), ctypes.byref(m))
+    if rc:
+        raise SnaphashError(rc)
+    return m.value
+
+
+def lpt_assign(lens, nshards):
+    import numpy as np
+    lens = np.ascontiguousarray(lens, dtype=np.uint64)
+    out = np.empty(len(lens), dtype=np.int32)
+    rc = lib().snaphash_lpt_assign(lens.ctypes.data, len(lens), nshards, out.ctypes.data)
+    if rc:
+        raise SnaphashError(rc)
+    return out

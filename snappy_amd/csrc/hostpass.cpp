@@ -1,0 +1,391 @@
+// hostpass.cpp -- the host-side half of the hashes.yaml pass: tree walk, record
+// model, yaml.v2-compatible emitter, tolerant parser, shard assignment.
+// No device code and no hashing here (digests come from the HIP kernels).
+//
+// Mirrors, from the reference tree:
+//   snappy/build.go:228-259    the filepath.Walk callback of writeHashes
+//   snappy/hashes.go:33-88     yamlFileMode.MarshalYAML / UnmarshalYAML
+//   snappy/hashes.go:93-110    fileHash / hashesYaml field order and omitempty
+//   snappy/hashes_test.go:89-103  the byte layout yaml.v2 gives that schema
+#include "hostpass.h"
+
+#include <dirent.h>
+#include <errno.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <queue>
+
+namespace snaphash {
+
+// ---- yamlFileMode -------------------------------------------------------------
+
+int mode_string(uint32_t st_mode, char out[11])
+{
+    memcpy(out, "----------", 11);
+    // Go: ModeDir -> 'd', ModeSymlink -> 'l', (mode & ModeType)==0 -> 'f',
+    // anything else (device, fifo, socket) -> "Unknown file mode" (hashes.go:36-47)
+    if (S_ISDIR(st_mode)) out[0] = 'd';
+    else if (S_ISLNK(st_mode)) out[0] = 'l';
+    else if (S_ISREG(st_mode)) out[0] = 'f';
+    else return SNAPHASH_EMODE;
+    static const char rwx[] = "rwxrwxrwx";
+    for (int i = 0; i < 9; ++i)
+        if (st_mode & (1u << (8 - i))) out[i + 1] = rwx[i]; // setuid/setgid/sticky are not in Go's low 9 bits
+    return SNAPHASH_OK;
+}
+
+int mode_parse(const char* s, uint32_t* st_mode)
+{
+    if (!s || !s[0]) return SNAPHASH_EPARSE; // the reference indexes modeAsStr[0] unguarded (hashes.go:67)
+    uint32_t m;
+    switch (s[0]) {
+    case 'd': m = S_IFDIR; break;
+    case 'f': m = S_IFREG; break;
+    case 'l': m = S_IFLNK; break;
+    default: return SNAPHASH_EPARSE;
+    }
+    static const char rwx[] = "rwxrwxrwx";
+    for (int i = 0; i < 9 && s[i + 1]; ++i)
+        if (s[i + 1] == rwx[i]) m |= 1u << (8 - i); // a perm char counts iff it is the expected letter (hashes.go:81-85)
+    *st_mode = m;
+    return SNAPHASH_OK;
+}
+
+// ---- filepath.Walk as writeHashes drives it ------------------------------------
+
+static int walk_rec(const std::string& path, size_t rootlen, std::vector<Record>& out, int* err_no)
+{
+    struct stat st;
+    if (lstat(path.c_str(), &st) != 0) { *err_no = errno; return SNAPHASH_EIO; }
+    const char* rel = path.c_str() + rootlen;
+    // build.go:229: string prefix, not path component -- "/DEBIAN-extra" is skipped too;
+    // build.go:232: the root itself.  The callback returns nil (not SkipDir), so
+    // Walk still descends into DEBIAN and skips its children one by one.
+    const bool skip = rel[0] == 0 || strncmp(rel, "/DEBIAN", 7) == 0;
+    if (!skip) {
+        Record r;
+        r.name = rel + 1; // build.go:250
+        r.path = path;
+        r.st_mode = st.st_mode;
+        r.is_regular = S_ISREG(st.st_mode); // build.go:240
+        r.size = r.is_regular ? (int64_t)st.st_size : 0;
+        char m[11];
+        if (mode_string(st.st_mode, m) != SNAPHASH_OK) return SNAPHASH_EMODE;
+        out.push_back(std::move(r));
+    }
+    if (!S_ISDIR(st.st_mode)) return SNAPHASH_OK;
+    DIR* d = opendir(path.c_str());
+    if (!d) { *err_no = errno; return SNAPHASH_EIO; }
+    std::vector<std::string> names;
+    while (struct dirent* de = readdir(d)) {
+        if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
+        names.emplace_back(de->d_name);
+    }
+    closedir(d);
+    std::sort(names.begin(), names.end()); // sort.Strings: byte-wise
+    for (const std::string& n : names) {
+        int rc = walk_rec(path + "/" + n, rootlen, out, err_no);
+        if (rc) return rc;
+    }
+    return SNAPHASH_OK;
+}
+
+int walk_tree(const char* build_dir, std::vector<Record>& out, int* err_no)
+{
+    std::string root(build_dir);
+    while (root.size() > 1 && root.back() == '/') root.pop_back();
+    int e = 0;
+    int rc = walk_rec(root, root.size(), out, &e);
+    if (err_no) *err_no = e;
+    return rc;
+}
+
+// ---- yaml.v2 emitter for hashesYaml ---------------------------------------------
+
+// The only scalar style the reference pins is the plain one
+// (hashes_test.go:89-103).  yaml.v2 quotes or tags scalars that would resolve to
+// another type or that libyaml's analyzer rejects as plain; those rules are not
+// pinned by any reference test, so names outside this conservative set are
+// refused (SNAPHASH_ENAME) rather than guessed at.
+bool plain_safe_name(const std::string& s)
+{
+    if (s.empty() || s.size() > 1000) return false;
+    bool alpha = false;
+    for (unsigned char c : s) {
+        const bool ok = (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_' ||
+                        c == '.' || c == '/' || c == '-' || c == '+';
+        if (!ok) return false;
+        if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) alpha = true;
+    }
+    const unsigned char c0 = s[0];
+    if (c0 == '-' || c0 == '.' || c0 == '+' || (c0 >= '0' && c0 <= '9')) return false;
+    if (!alpha) return false;
+    static const char* const resolved[] = {"y", "Y", "yes", "Yes", "YES", "on", "On", "ON", "n", "N", "no", "No", "NO",
+                                           "off", "Off", "OFF", "true", "True", "TRUE", "false", "False", "FALSE",
+                                           "null", "Null", "NULL", nullptr};
+    for (int i = 0; resolved[i]; ++i)
+        if (s == resolved[i]) return false;
+    return true;
+}
+
+void hex_lower(const uint8_t d[64], char out[128])
+{
+    static const char x[] = "0123456789abcdef"; // encoding/hex: lowercase (helpers.go:200)
+    for (int i = 0; i < 64; ++i) { out[2 * i] = x[d[i] >> 4]; out[2 * i + 1] = x[d[i] & 15]; }
+}
+
+int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64], const uint8_t* file_digests,
+              std::string& out)
+{
+    char hex[128];
+    out.clear();
+    out.reserve(64 + recs.size() * 220);
+    hex_lower(archive_digest, hex);
+    out += "archive-sha512: "; // hashes.go:106
+    out.append(hex, 128);
+    out += '\n';
+    if (recs.empty()) { // yaml.v2 renders an empty slice in flow style (unpinned by the reference)
+        out += "files: []\n";
+        return SNAPHASH_OK;
+    }
+    out += "files:\n"; // untagged field Files -> lower-cased key (hashes.go:109)
+    size_t fi = 0;
+    char num[32];
+    for (const Record& r : recs) {
+        if (!plain_safe_name(r.name)) return SNAPHASH_ENAME;
+        char mode[11];
+        int rc = mode_string(r.st_mode, mode);
+        if (rc) return rc;
+        out += "- name: "; out += r.name; out += '\n';
+        if (r.is_regular) { // size (*int64, omitempty on nil only: "size: 0" IS emitted), then sha512
+            snprintf(num, sizeof num, "%lld", (long long)r.size);
+            out += "  size: "; out += num; out += '\n';
+            hex_lower(file_digests + 64 * fi++, hex);
+            out += "  sha512: "; out.append(hex, 128); out += '\n';
+        }
+        out += "  mode: "; out.append(mode, 10); out += '\n';
+    }
+    return SNAPHASH_OK;
+}
+
+// ---- tolerant parser for yaml.v2's rendering of hashesYaml ------------------------
+
+namespace {
+
+int hexval(int c)
+{
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+    return -1;
+}
+
+// Scalar after "key: ".  Plain, 'single' or "double" quoted; no multi-line forms.
+bool parse_scalar(const std::string& v, std::string& out)
+{
+    out.clear();
+    if (v.empty()) return true;
+    if (v[0] == '\'') {
+        size_t i = 1;
+        for (; i < v.size(); ++i) {
+            if (v[i] == '\'') {
+                if (i + 1 < v.size() && v[i + 1] == '\'') { out += '\''; ++i; continue; }
+                break;
+            }
+            out += v[i];
+        }
+        return i < v.size();
+    }
+    if (v[0] == '"') {
+        size_t i = 1;
+        for (; i < v.size() && v[i] != '"'; ++i) {
+            if (v[i] != '\\') { out += v[i]; continue; }
+            if (++i >= v.size()) return false;
+            switch (v[i]) {
+            case 'n': out += '\n'; break;
+            case 't': out += '\t'; break;
+            case 'r': out += '\r'; break;
+            case '0': out += '\0'; break;
+            case 'a': out += '\a'; break;
+            case 'b': out += '\b'; break;
+            case 'e': out += '\x1b'; break;
+            case 'f': out += '\f'; break;
+            case 'v': out += '\v'; break;
+            case ' ': out += ' '; break;
+            case '"': out += '"'; break;
+            case '/': out += '/'; break;
+            case '\\': out += '\\'; break;
+            case 'x': case 'u': case 'U': {
+                const int nd = v[i] == 'x' ? 2 : (v[i] == 'u' ? 4 : 8);
+                if (i + nd >= v.size()) return false;
+                uint32_t cp = 0;
+                for (int k = 0; k < nd; ++k) {
+                    const int h = hexval(v[i + 1 + k]);
+                    if (h < 0) return false;
+                    cp = cp * 16 + h;
+                }
+                i += nd;
+                if (cp < 0x80) out += (char)cp; // UTF-8 encode
+                else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 63)); }
+                else if (cp < 0x10000) { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 63)); out += (char)(0x80 | (cp & 63)); }
+                else { out += (char)(0xF0 | (cp >> 18)); out += (char)(0x80 | ((cp >> 12) & 63)); out += (char)(0x80 | ((cp >> 6) & 63)); out += (char)(0x80 | (cp & 63)); }
+                break;
+            }
+            default: return false;
+            }
+        }
+        return i < v.size();
+    }
+    // plain: strip a trailing " #comment" and trailing spaces
+    std::string p = v;
+    size_t h = p.find(" #");
+    if (h != std::string::npos) p.resize(h);
+    while (!p.empty() && (p.back() == ' ' || p.back() == '\t' || p.back() == '\r')) p.pop_back();
+    out = p;
+    return true;
+}
+
+bool split_key(const std::string& line, size_t from, std::string& key, std::string& val)
+{
+    size_t c = line.find(':', from);
+    if (c == std::string::npos) return false;
+    key = line.substr(from, c - from);
+    size_t v = c + 1;
+    while (v < line.size() && line[v] == ' ') ++v;
+    val = line.substr(v);
+    while (!val.empty() && (val.back() == '\r' || val.back() == ' ')) val.pop_back();
+    return true;
+}
+
+bool unhex64(const std::string& s, uint8_t out[64])
+{
+    if (s.size() != 128) return false;
+    for (int i = 0; i < 64; ++i) {
+        const int a = hexval(s[2 * i]), b = hexval(s[2 * i + 1]);
+        if (a < 0 || b < 0) return false;
+        out[i] = (uint8_t)(a * 16 + b);
+    }
+    return true;
+}
+
+} // namespace
+
+int parse_yaml(const char* text, size_t len, ParsedHashes& out)
+{
+    out = ParsedHashes();
+    std::vector<std::string> lines;
+    {
+        size_t i = 0;
+        while (i < len) {
+            size_t j = i;
+            while (j < len && text[j] != '\n') ++j;
+            lines.emplace_back(text + i, j - i);
+            i = j + 1;
+        }
+    }
+    bool in_files = false;
+    int skip_indent = -1; // inside a nested block we ignore (xattr)
+    ParsedRecord* cur = nullptr;
+    for (const std::string& raw : lines) {
+        std::string line = raw;
+        while (!line.empty() && (line.back() == '\r')) line.pop_back();
+        size_t ind = 0;
+        while (ind < line.size() && line[ind] == ' ') ++ind;
+        if (ind == line.size() || line[ind] == '#') continue;
+        if (line == "---" || line == "...") continue;
+        if (skip_indent >= 0) {
+            if ((int)ind > skip_indent) continue;
+            skip_indent = -1;
+        }
+        std::string key, val, sv;
+        if (ind == 0 && line[0] != '-') { // top-level key
+            if (line == "{}") continue;   // common_test.go:77-80: an empty document is acceptable
+            if (!split_key(line, 0, key, val)) return SNAPHASH_EPARSE;
+            in_files = false;
+            cur = nullptr;
+            if (key == "archive-sha512") {
+                if (!parse_scalar(val, sv)) return SNAPHASH_EPARSE;
+                out.archive_hex = sv;
+                out.has_archive = true;
+            } else if (key == "files") {
+                if (val == "[]" || val == "") in_files = (val == "");
+                else return SNAPHASH_EPARSE;
+            } else if (val.empty()) {
+                skip_indent = 0; // unknown nested block
+            }
+            continue;
+        }
+        if (!in_files) return SNAPHASH_EPARSE;
+        size_t kstart = ind;
+        if (line[ind] == '-') { // new sequence item: "- key: value"
+            out.files.emplace_back();
+            cur = &out.files.back();
+            kstart = ind + 1;
+            while (kstart < line.size() && line[kstart] == ' ') ++kstart;
+            if (kstart >= line.size()) continue;
+        }
+        if (!cur) return SNAPHASH_EPARSE;
+        if (!split_key(line, kstart, key, val)) return SNAPHASH_EPARSE;
+        if (key == "xattr") { // map[string]string, unused upstream (hashes.go:98-100)
+            if (val.empty()) skip_indent = (int)kstart;
+            continue;
+        }
+        if (!parse_scalar(val, sv)) return SNAPHASH_EPARSE;
+        if (key == "name") { cur->name = sv; cur->has_name = true; }
+        else if (key == "size") {
+            if (sv.empty()) return SNAPHASH_EPARSE;
+            char* end = nullptr;
+            errno = 0;
+            long long v = strtoll(sv.c_str(), &end, 10);
+            if (errno || !end || *end) return SNAPHASH_EPARSE;
+            cur->size = v; cur->has_size = true;
+        } else if (key == "sha512") { cur->sha512_hex = sv; }
+        else if (key == "mode") {
+            if (mode_parse(sv.c_str(), &cur->st_mode) != SNAPHASH_OK) return SNAPHASH_EPARSE;
+            cur->has_mode = true;
+        }
+        // unknown keys are ignored, as yaml.v2 does for non-strict Unmarshal
+    }
+    for (const ParsedRecord& r : out.files)
+        if (!r.has_name || !r.has_mode) return SNAPHASH_EPARSE;
+    if (out.has_archive && !out.archive_hex.empty()) {
+        // stays a string: the reader side only carries it (snapp.go:466-478)
+    }
+    return SNAPHASH_OK;
+}
+
+bool digest_matches_hex(const uint8_t d[64], const std::string& hex)
+{
+    uint8_t e[64];
+    if (!unhex64(hex, e)) return false;
+    return memcmp(d, e, 64) == 0;
+}
+
+// ---- shard assignment --------------------------------------------------------------
+
+// LPT (longest processing time first): sort by SHA-512 block count descending,
+// give each file to the currently lightest shard.  Ties broken by index so the
+// result is deterministic on every rank.
+int lpt_assign(const uint64_t* lens, size_t n, int nshards, int32_t* shard_of)
+{
+    if (nshards <= 0 || (!lens && n) || (!shard_of && n)) return SNAPHASH_EINVAL;
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    auto blocks = [&](uint32_t i) { return (lens[i] + 17 + 127) / 128; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return blocks(a) > blocks(b); });
+    typedef std::pair<uint64_t, int> Load; // (blocks so far, shard)
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int s = 0; s < nshards; ++s) heap.push(Load(0, s));
+    for (uint32_t i : order) {
+        Load l = heap.top();
+        heap.pop();
+        shard_of[i] = l.second;
+        l.first += blocks(i);
+        heap.push(l);
+    }
+    return SNAPHASH_OK;
+}
+
+} // namespace snaphash

@@ -1,0 +1,44 @@
+// hostpass.h -- internal C++ interface of the host-side pass (walk, YAML, LPT).
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/snaphash.h"
+
+namespace snaphash {
+
+struct Record {          // one fileHash (snappy/hashes.go:93-101) before hashing
+    std::string name;    // relative to the walk root
+    std::string path;    // root-joined
+    uint32_t st_mode = 0;
+    bool is_regular = false;
+    int64_t size = 0;
+};
+
+struct ParsedRecord {
+    std::string name, sha512_hex;
+    int64_t size = 0;
+    uint32_t st_mode = 0;
+    bool has_name = false, has_size = false, has_mode = false;
+};
+struct ParsedHashes {
+    bool has_archive = false;
+    std::string archive_hex;
+    std::vector<ParsedRecord> files;
+};
+
+int mode_string(uint32_t st_mode, char out[11]);
+int mode_parse(const char* s, uint32_t* st_mode);
+int walk_tree(const char* build_dir, std::vector<Record>& out, int* err_no);
+bool plain_safe_name(const std::string& s);
+void hex_lower(const uint8_t d[64], char out[128]);
+int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64], const uint8_t* file_digests,
+              std::string& out);
+int parse_yaml(const char* text, size_t len, ParsedHashes& out);
+bool digest_matches_hex(const uint8_t d[64], const std::string& hex);
+int lpt_assign(const uint64_t* lens, size_t n, int nshards, int32_t* shard_of);
+
+} // namespace snaphash

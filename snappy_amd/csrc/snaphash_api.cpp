@@ -1,0 +1,729 @@
+// snaphash_api.cpp -- the C ABI of libsnaphash.so (include/snaphash.h): context,
+// HBM/pinned staging, the chunked double-buffered streaming engine that feeds
+// the multi-buffer SHA-512 kernels, and the writeHashes / Verify passes built
+// on it.
+//
+// Reference behaviour mirrored here (paths relative to the upstream tree):
+//   helpers/helpers.go:187-201  Sha512sum: whole-file digest, any read error fails
+//   snappy/build.go:216-270     writeHashes: archive digest first, then the walk;
+//                               the first error aborts, nothing is written
+// Hashing happens on the GPU only; there is no host fallback in this file.
+#include <errno.h>
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "hostpass.h"
+#include "sha512_core.h"
+#include "sha512_kernels.h"
+
+using namespace snaphash;
+
+namespace {
+
+constexpr uint64_t kDefaultStaging = 256ull << 20;
+constexpr uint64_t kAlign = 256;          // placement of a segment inside a staging buffer
+constexpr uint32_t kTargetStreams = 4096; // streams per batch the engine aims for (keeps the kernel ahead of PCIe)
+
+struct EventPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; }; // kind 0 kernel, 1 h2d
+
+struct Slot {
+    uint8_t* h_buf = nullptr; // pinned host
+    uint8_t* d_buf = nullptr; // HBM
+    Job* h_jobs = nullptr;    // pinned
+    Job* d_jobs = nullptr;
+    size_t jobs_cap = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+struct snaphash_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t staging = kDefaultStaging;
+    uint32_t kernel_pref = SNAPHASH_KERNEL_AUTO;
+
+    Slot slot[2];
+    // device-resident entry point
+    Job* h_jobs = nullptr; // pinned
+    Job* d_jobs = nullptr;
+    size_t jobs_cap = 0;
+    uint64_t* d_state = nullptr;
+    size_t state_cap = 0; // streams
+    uint8_t* d_digests = nullptr;
+    size_t digests_cap = 0; // streams
+
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    bool pending = false;
+
+    snaphash_stats stats{};
+    double t_call0 = 0;
+    std::string last_error;
+};
+
+namespace {
+
+int fail(snaphash_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->last_error = msg;
+    return code;
+}
+#define HIP_TRY(c, expr)                                                                             \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(c, (e_ == hipErrorOutOfMemory) ? SNAPHASH_ENOMEM : SNAPHASH_EDEVICE,         \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+    } while (0)
+
+EventPair* next_events(snaphash_ctx* c, int kind)
+{
+    if (c->ev_used == c->ev_pool.size()) {
+        EventPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(p);
+    }
+    EventPair* p = &c->ev_pool[c->ev_used++];
+    p->kind = kind;
+    return p;
+}
+
+void collect_events(snaphash_ctx* c)
+{
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) {
+            if (c->ev_pool[i].kind == 0) c->stats.kernel_ms += ms;
+            else c->stats.h2d_ms += ms;
+        }
+    }
+    c->ev_used = 0;
+}
+
+int ensure_state(snaphash_ctx* c, size_t n, bool want_digests)
+{
+    if (n > c->state_cap) {
+        if (c->d_state) (void)hipFree(c->d_state);
+        c->d_state = nullptr; c->state_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_state, n * 64));
+        c->state_cap = n;
+    }
+    if (want_digests && n > c->digests_cap) {
+        if (c->d_digests) (void)hipFree(c->d_digests);
+        c->d_digests = nullptr; c->digests_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_digests, n * 64));
+        c->digests_cap = n;
+    }
+    return SNAPHASH_OK;
+}
+
+int ensure_jobs(snaphash_ctx* c, Job** h, Job** d, size_t* cap, size_t n)
+{
+    if (n <= *cap) return SNAPHASH_OK;
+    size_t want = std::max<size_t>(n, 1024);
+    if (*h) (void)hipHostFree(*h);
+    if (*d) (void)hipFree(*d);
+    *h = nullptr; *d = nullptr; *cap = 0;
+    HIP_TRY(c, hipHostMalloc((void**)h, want * sizeof(Job), hipHostMallocDefault));
+    HIP_TRY(c, hipMalloc((void**)d, want * sizeof(Job)));
+    *cap = want;
+    return SNAPHASH_OK;
+}
+
+int ensure_slots(snaphash_ctx* c)
+{
+    for (Slot& s : c->slot) {
+        if (!s.h_buf) HIP_TRY(c, hipHostMalloc((void**)&s.h_buf, c->staging, hipHostMallocDefault));
+        if (!s.d_buf) HIP_TRY(c, hipMalloc((void**)&s.d_buf, c->staging));
+        if (!s.done) HIP_TRY(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    return SNAPHASH_OK;
+}
+
+uint32_t pick_kernel(const snaphash_ctx* c, size_t /*nstreams*/)
+{
+    if (c->kernel_pref == SNAPHASH_KERNEL_WIDE || c->kernel_pref == SNAPHASH_KERNEL_PAIR) return c->kernel_pref;
+    return SNAPHASH_KERNEL_WIDE;
+}
+
+// Sort (longest first, so the 64 lanes of a wave finish together), upload and launch.
+int launch_jobs(snaphash_ctx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_digests)
+{
+    if (n == 0) return SNAPHASH_OK;
+    std::stable_sort(h_jobs, h_jobs + n, [](const Job& a, const Job& b) { return a.nbytes > b.nbytes; });
+    HIP_TRY(c, hipMemcpyAsync(d_jobs, h_jobs, n * sizeof(Job), hipMemcpyHostToDevice, c->stream));
+    EventPair* ev = next_events(c, 0);
+    if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
+    HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+    const uint32_t k = pick_kernel(c, n);
+    hipError_t e = launch_wide(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
+    if (e != hipSuccess) return fail(c, SNAPHASH_EDEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+    HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+    c->stats.launches++;
+    c->stats.kernel_used = k == SNAPHASH_KERNEL_PAIR ? SNAPHASH_KERNEL_PAIR : SNAPHASH_KERNEL_WIDE;
+    c->pending = true;
+    return SNAPHASH_OK;
+}
+
+int sync_ctx(snaphash_ctx* c)
+{
+    if (!c->pending && c->ev_used == 0) return SNAPHASH_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    collect_events(c);
+    c->pending = false;
+    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    return SNAPHASH_OK;
+}
+
+void begin_call(snaphash_ctx* c)
+{
+    c->stats = snaphash_stats{};
+    c->t_call0 = now_ms();
+    c->last_error.clear();
+}
+
+// ---- streaming engine: host sources -> staged chunks -> kernels -----------------
+
+struct Source {
+    const char* path = nullptr;   // file source
+    const uint8_t* mem = nullptr; // memory source
+    uint64_t len = 0;
+};
+
+struct ReadOp { uint32_t src; uint64_t off; uint64_t n; uint8_t* dst; };
+
+void run_reads(const std::vector<Source>& src, const std::vector<ReadOp>& ops, std::atomic<int>& first_err,
+               std::atomic<int64_t>& first_err_src)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, ops.size() / 4));
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= ops.size() || first_err.load()) return;
+            const ReadOp& op = ops[i];
+            const Source& s = src[op.src];
+            if (s.mem) { memcpy(op.dst, s.mem + op.off, op.n); continue; }
+            int err = 0;
+            int fd = open(s.path, O_RDONLY | O_CLOEXEC);
+            if (fd < 0) err = errno;
+            uint64_t got = 0;
+            while (!err && got < op.n) {
+                ssize_t r = pread(fd, op.dst + got, op.n - got, (off_t)(op.off + got));
+                if (r < 0) { if (errno == EINTR) continue; err = errno; }
+                else if (r == 0) err = EIO; // file shrank underneath us
+                else got += (uint64_t)r;
+            }
+            if (fd >= 0) close(fd);
+            if (err) {
+                int z = 0;
+                if (first_err.compare_exchange_strong(z, err)) first_err_src.store(op.src);
+                return;
+            }
+        }
+    };
+    if (T <= 1) { worker(); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+}
+
+int hash_sources(snaphash_ctx* c, const std::vector<Source>& src, uint8_t* digests, int32_t* status)
+{
+    const size_t n = src.size();
+    if (n == 0) return SNAPHASH_OK;
+    int rc = ensure_slots(c);
+    if (rc) return rc;
+    rc = ensure_state(c, n, true);
+    if (rc) return rc;
+
+    std::vector<uint64_t> done(n, 0);
+    std::vector<uint32_t> active(n);
+    for (size_t i = 0; i < n; ++i) active[i] = (uint32_t)i;
+    std::atomic<int> first_err{0};
+    std::atomic<int64_t> first_err_src{-1};
+    std::vector<ReadOp> ops;
+    const uint64_t S = c->staging;
+    unsigned batch = 0;
+
+    while (!active.empty()) {
+        Slot& sl = c->slot[batch & 1];
+        if (sl.busy) { HIP_TRY(c, hipEventSynchronize(sl.done)); sl.busy = false; }
+        const uint64_t target = std::min<uint64_t>(active.size(), kTargetStreams);
+        uint64_t quota = (S / target) & ~(uint64_t)(kAlign - 1);
+        if (quota < kAlign) quota = kAlign;
+        rc = ensure_jobs(c, &sl.h_jobs, &sl.d_jobs, &sl.jobs_cap, active.size());
+        if (rc) return rc;
+
+        ops.clear();
+        size_t nj = 0;
+        uint64_t used = 0;
+        std::vector<uint32_t> still;
+        still.reserve(active.size());
+        bool full = false;
+        for (uint32_t id : active) {
+            if (full) { still.push_back(id); continue; }
+            const uint64_t rem = src[id].len - done[id];
+            const uint64_t take = rem <= quota ? rem : quota; // quota is a multiple of 128
+            const uint64_t at = (used + kAlign - 1) & ~(uint64_t)(kAlign - 1);
+            if (at + take > S) { full = true; still.push_back(id); continue; }
+            Job j;
+            j.data = (uint64_t)(uintptr_t)(sl.d_buf + at);
+            j.nbytes = take;
+            j.total_prev = done[id];
+            j.idx = id;
+            j.flags = (done[id] == 0 ? kJobFirst : 0u) | (take == rem ? kJobFinal : 0u);
+            sl.h_jobs[nj++] = j;
+            if (take) ops.push_back(ReadOp{id, done[id], take, sl.h_buf + at});
+            used = at + take;
+            done[id] += take;
+            c->stats.blocks += padded_blocks(take, take == rem);
+            if (take != rem) still.push_back(id);
+        }
+        active.swap(still);
+
+        run_reads(src, ops, first_err, first_err_src);
+        if (first_err.load()) break;
+
+        if (used) {
+            EventPair* ev = next_events(c, 1);
+            if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
+            HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, used, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+        }
+        rc = launch_jobs(c, sl.h_jobs, sl.d_jobs, nj, c->d_digests);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(sl.done, c->stream));
+        sl.busy = true;
+        ++batch;
+    }
+
+    rc = sync_ctx(c);
+    c->slot[0].busy = c->slot[1].busy = false;
+    if (rc) return rc;
+    if (first_err.load()) {
+        const int64_t s = first_err_src.load();
+        if (status) {
+            for (size_t i = 0; i < n; ++i) status[i] = 0;
+            if (s >= 0) status[s] = first_err.load();
+        }
+        return fail(c, SNAPHASH_EIO,
+                    std::string(s >= 0 && src[s].path ? src[s].path : "<buffer>") + ": " + strerror(first_err.load()));
+    }
+    HIP_TRY(c, hipMemcpy(digests, c->d_digests, n * 64, hipMemcpyDeviceToHost));
+    if (status) for (size_t i = 0; i < n; ++i) status[i] = 0;
+    for (size_t i = 0; i < n; ++i) c->stats.bytes_hashed += src[i].len;
+    c->stats.streams = n;
+    return SNAPHASH_OK;
+}
+
+int hash_paths(snaphash_ctx* c, const char* const* paths, size_t n, uint8_t* digests, int32_t* status)
+{
+    std::vector<Source> src(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (!paths[i]) return fail(c, SNAPHASH_EINVAL, "NULL path");
+        struct stat st;
+        int err = 0;
+        // os.Open follows symlinks (helpers.go:189); a directory opens but its read fails with EISDIR
+        if (stat(paths[i], &st) != 0) err = errno;
+        else if (S_ISDIR(st.st_mode)) err = EISDIR;
+        else if (access(paths[i], R_OK) != 0) err = errno;
+        if (err) {
+            if (status) { for (size_t k = 0; k < n; ++k) status[k] = 0; status[i] = err; }
+            return fail(c, SNAPHASH_EIO, std::string(paths[i]) + ": " + strerror(err));
+        }
+        src[i].path = paths[i];
+        src[i].len = (uint64_t)st.st_size;
+    }
+    return hash_sources(c, src, digests, status);
+}
+
+} // namespace
+
+// ================================== C ABI ==========================================
+
+extern "C" {
+
+int snaphash_abi_version(void) { return SNAPHASH_ABI_VERSION; }
+
+int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
+{
+    if (!out) return SNAPHASH_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SNAPHASH_EDEVICE;
+    int dev = -1;
+    if (cfg && cfg->struct_size >= sizeof(snaphash_config)) dev = cfg->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return SNAPHASH_EDEVICE;
+    if (dev >= ndev) return SNAPHASH_EINVAL;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SNAPHASH_EDEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SNAPHASH_EDEVICE; // the code object is gfx950-only
+    if (hipSetDevice(dev) != hipSuccess) return SNAPHASH_EDEVICE;
+    snaphash_ctx* c = new (std::nothrow) snaphash_ctx();
+    if (!c) return SNAPHASH_ENOMEM;
+    c->device = dev;
+    if (cfg && cfg->struct_size >= sizeof(snaphash_config)) {
+        if (cfg->staging_bytes) c->staging = (cfg->staging_bytes + kAlign - 1) & ~(uint64_t)(kAlign - 1);
+        c->kernel_pref = cfg->kernel;
+        if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
+    }
+    if (c->staging < (1u << 16)) c->staging = 1u << 16;
+    if (!c->stream) {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SNAPHASH_EDEVICE; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return SNAPHASH_OK;
+}
+
+void snaphash_destroy(snaphash_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (Slot& s : c->slot) {
+        if (s.h_buf) (void)hipHostFree(s.h_buf);
+        if (s.d_buf) (void)hipFree(s.d_buf);
+        if (s.h_jobs) (void)hipHostFree(s.h_jobs);
+        if (s.d_jobs) (void)hipFree(s.d_jobs);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (c->h_jobs) (void)hipHostFree(c->h_jobs);
+    if (c->d_jobs) (void)hipFree(c->d_jobs);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->d_digests) (void)hipFree(c->d_digests);
+    for (EventPair& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int snaphash_sha512_files(snaphash_ctx* c, const char* const* paths, size_t n, uint8_t* digests, int32_t* status)
+{
+    if (!c || (n && (!paths || !digests))) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = sync_ctx(c);
+    if (rc) return rc;
+    begin_call(c);
+    rc = hash_paths(c, paths, n, digests, status);
+    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    return rc;
+}
+
+int snaphash_sha512_buffers(snaphash_ctx* c, const void* const* bufs, const uint64_t* lens, size_t n, uint8_t* digests)
+{
+    if (!c || (n && (!bufs || !lens || !digests))) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = sync_ctx(c);
+    if (rc) return rc;
+    begin_call(c);
+    std::vector<Source> src(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (!bufs[i] && lens[i]) return fail(c, SNAPHASH_EINVAL, "NULL buffer with non-zero length");
+        src[i].mem = bufs[i] ? (const uint8_t*)bufs[i] : (const uint8_t*)"";
+        src[i].len = lens[i];
+    }
+    rc = hash_sources(c, src, digests, nullptr);
+    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    return rc;
+}
+
+int snaphash_sha512_device(snaphash_ctx* c, const void* d_base, const uint64_t* offsets, const uint64_t* lens,
+                           size_t n, void* d_digests)
+{
+    if (!c || (n && (!d_base || !offsets || !lens || !d_digests))) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    if (((uintptr_t)d_base & 15) != 0) return fail(c, SNAPHASH_EINVAL, "d_base must be 16-byte aligned");
+    if (n > 0xffffffffull) return fail(c, SNAPHASH_EINVAL, "too many streams");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = sync_ctx(c); // one call in flight per ctx: the pinned job array is reused
+    if (rc) return rc;
+    begin_call(c);
+    if (n == 0) return SNAPHASH_OK;
+    rc = ensure_state(c, n, false);
+    if (rc) return rc;
+    rc = ensure_jobs(c, &c->h_jobs, &c->d_jobs, &c->jobs_cap, n);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        if (offsets[i] & 15) return fail(c, SNAPHASH_EINVAL, "offsets must be 16-byte aligned");
+        Job& j = c->h_jobs[i];
+        j.data = (uint64_t)(uintptr_t)d_base + offsets[i];
+        j.nbytes = lens[i];
+        j.total_prev = 0;
+        j.idx = (uint32_t)i;
+        j.flags = kJobFirst | kJobFinal;
+        c->stats.bytes_hashed += lens[i];
+        c->stats.blocks += padded_blocks(lens[i], true);
+    }
+    c->stats.streams = n;
+    return launch_jobs(c, c->h_jobs, c->d_jobs, n, (uint8_t*)d_digests);
+}
+
+int snaphash_sync(snaphash_ctx* c)
+{
+    if (!c) return SNAPHASH_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return sync_ctx(c);
+}
+
+// ---- the pass -----------------------------------------------------------------------
+
+static int tree_impl(snaphash_ctx* c, const char* build_dir, const char* data_tar, std::string& yaml)
+{
+    // build.go:222 hashes the archive first; a missing archive fails before the walk
+    struct stat st;
+    if (stat(data_tar, &st) != 0) return fail(c, SNAPHASH_EIO, std::string(data_tar) + ": " + strerror(errno));
+    std::vector<Record> recs;
+    int en = 0;
+    int rc = walk_tree(build_dir, recs, &en);
+    if (rc) return fail(c, rc, rc == SNAPHASH_EIO ? std::string(build_dir) + ": " + strerror(en) : "Unknown file mode");
+    for (const Record& r : recs)
+        if (!plain_safe_name(r.name)) return fail(c, SNAPHASH_ENAME, "name needs YAML quoting: " + r.name);
+    std::vector<const char*> paths;
+    paths.push_back(data_tar); // element 0 = the archive, as in the Go batch shape
+    for (const Record& r : recs)
+        if (r.is_regular) paths.push_back(r.path.c_str());
+    std::vector<uint8_t> dig(paths.size() * 64);
+    rc = hash_paths(c, paths.data(), paths.size(), dig.data(), nullptr);
+    if (rc) return rc;
+    // io.Copy reads to EOF, info.Size() comes from lstat: a file that grew or shrank
+    // between the two is an error here rather than a silently inconsistent record.
+    return emit_yaml(recs, dig.data(), dig.data() + 64, yaml);
+}
+
+int snaphash_tree(snaphash_ctx* c, const char* build_dir, const char* data_tar, char** yaml_out, size_t* yaml_len)
+{
+    if (!c || !build_dir || !data_tar || !yaml_out) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = sync_ctx(c);
+    if (rc) return rc;
+    begin_call(c);
+    std::string y;
+    rc = tree_impl(c, build_dir, data_tar, y);
+    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    if (rc) return rc;
+    char* p = (char*)malloc(y.size() + 1);
+    if (!p) return fail(c, SNAPHASH_ENOMEM, "malloc");
+    memcpy(p, y.data(), y.size());
+    p[y.size()] = 0;
+    *yaml_out = p;
+    if (yaml_len) *yaml_len = y.size();
+    return SNAPHASH_OK;
+}
+
+int snaphash_write_hashes(snaphash_ctx* c, const char* build_dir, const char* data_tar)
+{
+    if (!c || !build_dir || !data_tar) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    std::string dir = std::string(build_dir) + "/DEBIAN";
+    (void)mkdir(dir.c_str(), 0755); // os.MkdirAll(debianDir, 0755), error ignored (build.go:219)
+    char* y = nullptr;
+    size_t n = 0;
+    int rc = snaphash_tree(c, build_dir, data_tar, &y, &n);
+    if (rc) return rc; // nothing is written on error (build.go:260-267)
+    const std::string path = dir + "/hashes.yaml";
+    int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644); // ioutil.WriteFile(..., 0644)
+    if (fd < 0) { free(y); return fail(c, SNAPHASH_EIO, path + ": " + strerror(errno)); }
+    size_t off = 0;
+    while (off < n) {
+        ssize_t w = write(fd, y + off, n - off);
+        if (w < 0) { if (errno == EINTR) continue; int e = errno; close(fd); free(y); return fail(c, SNAPHASH_EIO, path + ": " + strerror(e)); }
+        off += (size_t)w;
+    }
+    close(fd);
+    free(y);
+    return SNAPHASH_OK;
+}
+
+static int mismatch(snaphash_ctx* c, snaphash_mismatch* m, int kind, const std::string& name)
+{
+    if (m) {
+        m->kind = kind;
+        m->reserved = 0;
+        snprintf(m->name, sizeof m->name, "%s", name.c_str());
+    }
+    static const char* const what[] = {"", "missing on disk", "not in hashes.yaml", "size differs", "sha512 differs",
+                                       "mode differs", "archive-sha512 differs"};
+    return fail(c, SNAPHASH_EMISMATCH, name + ": " + what[kind]);
+}
+
+int snaphash_verify(snaphash_ctx* c, const char* inst_dir, const char* data_tar, const char* yaml, size_t yaml_len,
+                    snaphash_mismatch* first)
+{
+    if (!c || !inst_dir || !yaml) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = sync_ctx(c);
+    if (rc) return rc;
+    begin_call(c);
+    ParsedHashes ph;
+    rc = parse_yaml(yaml, yaml_len, ph);
+    if (rc) return fail(c, rc, "hashes.yaml: parse error");
+    std::vector<Record> recs;
+    int en = 0;
+    rc = walk_tree(inst_dir, recs, &en);
+    if (rc) return fail(c, rc, rc == SNAPHASH_EIO ? std::string(inst_dir) + ": " + strerror(en) : "Unknown file mode");
+
+    // Both lists are in walk order (per-directory byte-wise pre-order), so a
+    // merge-style scan finds the first name present on one side only.
+    size_t i = 0, j = 0;
+    while (i < ph.files.size() && j < recs.size()) {
+        if (ph.files[i].name == recs[j].name) { ++i; ++j; continue; }
+        // decide which side is "extra": look the yaml name up on disk
+        bool on_disk = false;
+        for (size_t k = j; k < recs.size(); ++k)
+            if (recs[k].name == ph.files[i].name) { on_disk = true; break; }
+        return on_disk ? mismatch(c, first, 2, recs[j].name) : mismatch(c, first, 1, ph.files[i].name);
+    }
+    if (i < ph.files.size()) return mismatch(c, first, 1, ph.files[i].name);
+    if (j < recs.size()) return mismatch(c, first, 2, recs[j].name);
+
+    for (size_t k = 0; k < recs.size(); ++k) {
+        const ParsedRecord& p = ph.files[k];
+        const Record& r = recs[k];
+        char a[11], b[11];
+        if (mode_string(p.st_mode, a) || mode_string(r.st_mode, b) || memcmp(a, b, 10) != 0) return mismatch(c, first, 5, r.name);
+        if (r.is_regular) {
+            if (!p.has_size || p.size != r.size) return mismatch(c, first, 3, r.name);
+        } else if (p.has_size || !p.sha512_hex.empty()) {
+            return mismatch(c, first, 3, r.name);
+        }
+    }
+    std::vector<const char*> paths;
+    std::vector<size_t> owner;
+    const bool check_archive = data_tar && ph.has_archive;
+    if (check_archive) { paths.push_back(data_tar); owner.push_back((size_t)-1); }
+    for (size_t k = 0; k < recs.size(); ++k)
+        if (recs[k].is_regular) { paths.push_back(recs[k].path.c_str()); owner.push_back(k); }
+    std::vector<uint8_t> dig(paths.size() * 64);
+    rc = hash_paths(c, paths.data(), paths.size(), dig.data(), nullptr);
+    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    if (rc) return rc;
+    for (size_t q = 0; q < paths.size(); ++q) {
+        if (owner[q] == (size_t)-1) {
+            if (!digest_matches_hex(dig.data() + 64 * q, ph.archive_hex)) return mismatch(c, first, 6, "archive-sha512");
+        } else if (!digest_matches_hex(dig.data() + 64 * q, ph.files[owner[q]].sha512_hex)) {
+            return mismatch(c, first, 4, recs[owner[q]].name);
+        }
+    }
+    return SNAPHASH_OK;
+}
+
+void snaphash_free(void* p) { free(p); }
+
+// ---- host-side pieces ------------------------------------------------------------------
+
+struct snaphash_records { std::vector<Record> v; };
+
+int snaphash_walk(const char* build_dir, snaphash_records** out)
+{
+    if (!build_dir || !out) return SNAPHASH_EINVAL;
+    snaphash_records* r = new (std::nothrow) snaphash_records();
+    if (!r) return SNAPHASH_ENOMEM;
+    int en = 0;
+    int rc = walk_tree(build_dir, r->v, &en);
+    if (rc) { delete r; errno = en; return rc; }
+    *out = r;
+    return SNAPHASH_OK;
+}
+size_t snaphash_records_count(const snaphash_records* r) { return r ? r->v.size() : 0; }
+int snaphash_records_get(const snaphash_records* r, size_t i, snaphash_record* out)
+{
+    if (!r || !out || i >= r->v.size()) return SNAPHASH_EINVAL;
+    const Record& x = r->v[i];
+    out->name = x.name.c_str();
+    out->st_mode = x.st_mode;
+    out->is_regular = x.is_regular ? 1 : 0;
+    out->size = x.size;
+    out->path = x.path.c_str();
+    return SNAPHASH_OK;
+}
+void snaphash_records_free(snaphash_records* r) { delete r; }
+
+int snaphash_emit_yaml(const snaphash_records* r, const uint8_t archive_digest[64], const uint8_t* file_digests,
+                       char** yaml_out, size_t* yaml_len)
+{
+    if (!r || !archive_digest || !yaml_out) return SNAPHASH_EINVAL;
+    std::string y;
+    int rc = emit_yaml(r->v, archive_digest, file_digests, y);
+    if (rc) return rc;
+    char* p = (char*)malloc(y.size() + 1);
+    if (!p) return SNAPHASH_ENOMEM;
+    memcpy(p, y.data(), y.size());
+    p[y.size()] = 0;
+    *yaml_out = p;
+    if (yaml_len) *yaml_len = y.size();
+    return SNAPHASH_OK;
+}
+
+int snaphash_mode_string(uint32_t st_mode, char out[11]) { return out ? mode_string(st_mode, out) : SNAPHASH_EINVAL; }
+int snaphash_mode_parse(const char* s, uint32_t* st_mode) { return (s && st_mode) ? mode_parse(s, st_mode) : SNAPHASH_EINVAL; }
+int snaphash_lpt_assign(const uint64_t* lens, size_t n, int nshards, int32_t* shard_of) { return lpt_assign(lens, n, nshards, shard_of); }
+
+int snaphash_fill_synthetic_device(snaphash_ctx* c, void* d_base, const uint64_t* offsets, const uint64_t* lens,
+                                   const uint64_t* file_index, size_t n)
+{
+    if (!c || (n && (!d_base || !offsets || !lens || !file_index))) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    if (n == 0) return SNAPHASH_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint64_t* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, 3 * n * sizeof(uint64_t)));
+    uint64_t maxlen = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (offsets[i] & 7) { (void)hipFree(d); return fail(c, SNAPHASH_EINVAL, "offsets must be 8-byte aligned"); }
+        maxlen = std::max(maxlen, lens[i]);
+    }
+    hipError_t e = hipMemcpyAsync(d, offsets, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + n, lens, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + 2 * n, file_index, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_fill_synthetic((uint8_t*)d_base, d, d + n, d + 2 * n, (uint32_t)n, maxlen, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, SNAPHASH_EDEVICE, std::string("fill_synthetic: ") + hipGetErrorString(e));
+    return SNAPHASH_OK;
+}
+
+// ---- diagnostics ------------------------------------------------------------------------
+
+const char* snaphash_strerror(int code)
+{
+    switch (code) {
+    case SNAPHASH_OK: return "ok";
+    case SNAPHASH_EINVAL: return "invalid argument";
+    case SNAPHASH_ENOMEM: return "out of memory";
+    case SNAPHASH_EIO: return "i/o error";
+    case SNAPHASH_EDEVICE: return "no usable gfx950 device or HIP failure";
+    case SNAPHASH_EMODE: return "Unknown file mode";
+    case SNAPHASH_ENAME: return "file name outside the plain YAML scalar set";
+    case SNAPHASH_EPARSE: return "hashes.yaml parse error";
+    case SNAPHASH_EMISMATCH: return "tree does not match hashes.yaml";
+    default: return "unknown error";
+    }
+}
+
+const char* snaphash_last_error(const snaphash_ctx* c) { return c ? c->last_error.c_str() : ""; }
+
+void snaphash_get_stats(const snaphash_ctx* c, snaphash_stats* out)
+{
+    if (c && out) *out = c->stats;
+}
+
+} // extern "C"

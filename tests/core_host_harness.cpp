@@ -1,0 +1,51 @@
+// Test-only: compiles snappy_amd/csrc/sha512_core.h as host C++ and walks one
+// stream through it exactly as a kernel lane does (full blocks, then the padded
+// tail via apply_padding with garbage past the message end, optional segment
+// split with chaining-state carry).  Lets the CPU suite check the block/padding
+// logic the HIP kernels share; it is not part of the product.
+#include <string.h>
+
+#include "../snappy_amd/csrc/sha512_core.h"
+
+using namespace snaphash;
+
+static void load_block(uint64_t w[16], const uint8_t* p, uint32_t valid)
+{
+    uint8_t tmp[128];
+    memset(tmp, 0xAA, sizeof tmp); // what a lane may see past the end of its file
+    memcpy(tmp, p, valid);
+    for (int k = 0; k < 16; ++k) {
+        uint32_t d0, d1;
+        memcpy(&d0, tmp + 8 * k, 4);
+        memcpy(&d1, tmp + 8 * k + 4, 4);
+        w[k] = be64(d0, d1);
+    }
+}
+
+static void run_segment(uint64_t H[8], const uint8_t* data, uint64_t nbytes, uint64_t total_prev, bool fin)
+{
+    const uint32_t nfull = (uint32_t)(nbytes >> 7), rem = (uint32_t)(nbytes & 127);
+    const uint32_t nblk = padded_blocks(nbytes, fin);
+    for (uint32_t b = 0; b < nblk + 1; ++b) { // one extra dead iteration: live == false must not change H
+        uint64_t w[16];
+        if (b < nfull) load_block(w, data + 128ull * b, 128);
+        else if (b == nfull) load_block(w, data + 128ull * b, rem);
+        else load_block(w, data, 0);
+        apply_padding(w, b >= nfull, b - nfull, rem, total_prev + nbytes);
+        compress_block(H, w, b < nblk, K512);
+    }
+}
+
+extern "C" void core_sha512(const uint8_t* data, uint64_t len, uint64_t split, uint8_t out[64])
+{
+    uint64_t H[8];
+    for (int k = 0; k < 8; ++k) H[k] = IV512[k];
+    if (split && split < len && (split & 127) == 0) {
+        run_segment(H, data, split, 0, false);
+        run_segment(H, data + split, len - split, split, true);
+    } else {
+        run_segment(H, data, len, 0, true);
+    }
+    for (int i = 0; i < 8; ++i)
+        for (int b = 0; b < 8; ++b) out[8 * i + b] = (uint8_t)(H[i] >> (56 - 8 * b));
+}

@@ -1,0 +1,76 @@
+"""The N > 1 path on CPU: world_size-2 gloo ranks run the shard plan + digest
+gather (snappy_amd/sharded.py).  Hashing itself needs a GPU, so each rank's
+local digests come from the oracle here -- the test covers the partitioning and
+the collective, which are device-independent."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, sizes, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        from snappy_amd.sharded import ShardPlan, gather_digests
+        plan = ShardPlan(sizes, world)
+        mine = plan.members(rank)
+        slab = torch.zeros((plan.kmax, 64), dtype=torch.uint8)
+        for k, i in enumerate(mine):
+            d = oracle.sha512(oracle.fill_synthetic(int(sizes[i]), int(i)).tobytes())
+            slab[k] = torch.frombuffer(bytearray(d), dtype=torch.uint8)
+        full = gather_digests(slab, plan)
+        q.put((rank, full.numpy().tobytes(), [int(c) for c in plan.counts]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_and_gather_gloo(world, oracle):
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([rng.integers(0, 3000, size=41), [0, 128, 100000]]).astype(np.uint64)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, sizes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = b"".join(oracle.sha512(oracle.fill_synthetic(int(n), i).tobytes()) for i, n in enumerate(sizes))
+    for rank, blob, counts in res:
+        assert blob == want, rank               # every rank holds the full vector, in walk order
+        assert sum(counts) == len(sizes) and min(counts) > 0
+
+
+def test_plan_is_balanced_and_deterministic(built_lib):
+    from snappy_amd import synthetic
+    from snappy_amd.sharded import ShardPlan
+    sizes = np.tile(synthetic.config_sizes("C2"), 8)
+    p = ShardPlan(sizes, 8)
+    assert set(p.counts) == {10001}
+    assert sorted(p.row_of.tolist()) == list(range(8 * 10001))
+    z = ShardPlan(synthetic.zipf_sizes(20000), 8)
+    loads = np.array([synthetic.zipf_sizes(20000)[z.members(r)].sum() for r in range(8)], dtype=np.float64)
+    # the 256 MiB head file bounds the makespan from below; LPT stays within one head file of the mean
+    assert loads.max() <= max(loads.mean() + (1 << 28), 1 << 28)

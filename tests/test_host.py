@@ -1,0 +1,151 @@
+"""Host-side logic of libsnaphash.so (walk, YAML, modes, LPT) and the C-ABI
+surface.  CPU only: nothing here hashes through the library (that needs a GPU);
+where a digest is needed to exercise the emitter it is supplied by the oracle,
+which is its role as checker."""
+import ctypes
+import os
+import re
+import stat
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+import trees
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from snappy_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "snaphash.h")).read()
+    declared = set(re.findall(r"\b(snaphash_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS)
+    for s in declared:
+        assert hasattr(built_lib, s), s
+    assert built_lib.snaphash_abi_version() == 1
+
+
+def test_struct_layouts_match_header(built_lib):
+    from snappy_amd import _lib
+    assert ctypes.sizeof(_lib.Config) == 32
+    assert ctypes.sizeof(_lib.Stats) == 56
+    assert ctypes.sizeof(_lib.Mismatch) == 8 + 4096
+    assert ctypes.sizeof(_lib.Record) == 32
+
+
+def test_no_gpu_means_loud_failure(built_lib):
+    """Without a usable gfx950 device the product refuses to start: no CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from snappy_amd import Context, SnaphashError, _lib
+    with pytest.raises(SnaphashError) as e:
+        Context()
+    assert e.value.code == _lib.EDEVICE
+
+
+def test_product_never_touches_the_oracle():
+    """The package must not import, link or shell out to oracle/."""
+    pkg = os.path.join(ROOT, "snappy_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower() or f == "README.md", os.path.join(dirpath, f)
+
+
+def test_walk_matches_reference_rules(built_lib, tmp_path):
+    from snappy_amd import _lib
+    b = tmp_path / "b"
+    for d in ("a", "DEBIAN", "DEBIAN-extra", "sub/DEBIAN"):
+        (b / d).mkdir(parents=True)
+    for f in ("a/x", "a-b", "DEBIANfoo", "DEBIAN/control", "DEBIAN-extra/y", "sub/DEBIAN/kept", "debian"):
+        (b / f).write_bytes(f.encode())
+    os.symlink("a", str(b / "link-to-dir"))  # dir symlinks are not descended (Lstat)
+    recs = _lib.walk(str(b))
+    assert [r["name"] for r in recs] == ["a", "a/x", "a-b", "debian", "link-to-dir", "sub", "sub/DEBIAN",
+                                         "sub/DEBIAN/kept"]
+    by = {r["name"]: r for r in recs}
+    assert by["a/x"]["is_regular"] and by["a/x"]["size"] == 3
+    assert not by["a"]["is_regular"] and not by["link-to-dir"]["is_regular"]
+    assert stat.S_ISLNK(by["link-to-dir"]["st_mode"])
+    # trailing slash on the root is tolerated
+    assert [r["name"] for r in _lib.walk(str(b) + "/")] == [r["name"] for r in recs]
+
+
+def test_walk_fifo_is_unknown_mode(built_lib, tmp_path):
+    from snappy_amd import _lib, SnaphashError
+    b = tmp_path / "b"
+    b.mkdir()
+    os.mkfifo(str(b / "pipe"))
+    with pytest.raises(SnaphashError) as e:
+        _lib.walk(str(b))
+    assert e.value.code == _lib.EMODE
+
+
+def test_emit_golden_yaml_byte_for_byte(built_lib, oracle, tmp_path):
+    """snappy/hashes_test.go:89-103 through the product's walk + emitter."""
+    from snappy_amd import _lib
+    build, tar = trees.make_simple_tree(str(tmp_path))
+    recs = _lib.walk(build)
+    digs = [oracle.sha512(open(r["path"], "rb").read()) for r in recs if r["is_regular"]]
+    y = _lib.emit_yaml(build, oracle.sha512(b""), digs)
+    assert y == open(os.path.join(GOLDEN, "hashes_simple.yaml"), "rb").read()
+
+
+def test_emit_matches_oracle_on_synthetic_tree(built_lib, oracle, tmp_path):
+    from snappy_amd import _lib
+    build, tar = trees.make_synthetic_tree(str(tmp_path), [0, 1, 127, 128, 129, 4096, 70000, 333, 1000])
+    recs = _lib.walk(build)
+    digs = [oracle.sha512(open(r["path"], "rb").read()) for r in recs if r["is_regular"]]
+    y = _lib.emit_yaml(build, oracle.sha512(open(tar, "rb").read()), digs)
+    assert y == oracle.hashes_yaml(build, tar)
+
+
+def test_emit_empty_and_unsafe(built_lib, oracle, tmp_path):
+    from snappy_amd import _lib, SnaphashError
+    b = tmp_path / "b"
+    b.mkdir()
+    assert _lib.emit_yaml(str(b), oracle.sha512(b""), []).endswith(b"files: []\n")
+    for bad in ("has space", "123", "true", "-dash", "colon:x", "café", "~", "#c"):
+        (b / bad).write_bytes(b"")
+        with pytest.raises(SnaphashError) as e:
+            _lib.emit_yaml(str(b), oracle.sha512(b""), [oracle.sha512(b"")])
+        assert e.value.code == _lib.ENAME, bad
+        os.unlink(str(b / bad))
+
+
+def test_mode_roundtrip(built_lib):
+    from snappy_amd import _lib, SnaphashError, yamlFileMode
+    # snappy/hashes_test.go:30-55: fileHash{Mode: 0644|ModeDir} <-> "drw-r--r--"
+    assert _lib.mode_string(stat.S_IFDIR | 0o644) == "drw-r--r--"
+    assert yamlFileMode.UnmarshalYAML("drw-r--r--") == yamlFileMode(stat.S_IFDIR | 0o644)
+    for m in (stat.S_IFREG | 0o644, stat.S_IFREG | 0o755, stat.S_IFDIR | 0o755, stat.S_IFLNK | 0o777,
+              stat.S_IFREG | 0o000, stat.S_IFREG | 0o4711):
+        s = _lib.mode_string(m)
+        assert len(s) == 10
+        back = _lib.mode_parse(s)
+        assert stat.S_IFMT(back) == stat.S_IFMT(m) and back & 0o777 == m & 0o777
+    assert _lib.mode_string(stat.S_IFREG | 0o4755) == "frwxr-xr-x"
+    # a perm char counts only if it is the expected letter at that position (hashes.go:81-85)
+    assert _lib.mode_parse("fxxxxxxxxx") & 0o777 == 0o111
+    for bad in ("", "x---------", "-rw-r--r--"):
+        with pytest.raises(SnaphashError):
+            _lib.mode_parse(bad)
+    for bad in (stat.S_IFIFO, stat.S_IFSOCK, stat.S_IFCHR, stat.S_IFBLK):
+        with pytest.raises(SnaphashError):
+            _lib.mode_string(bad | 0o600)
+
+
+def test_lpt_assign(built_lib):
+    import numpy as np
+    from snappy_amd import _lib, synthetic
+    lens = synthetic.zipf_sizes(5000)
+    for k in (1, 2, 4, 8):
+        s = _lib.lpt_assign(lens, k)
+        assert s.min() >= 0 and s.max() < k
+        blocks = (lens + np.uint64(17 + 127)) // np.uint64(128)
+        loads = np.array([blocks[s == r].sum() for r in range(k)], dtype=np.float64)
+        # LPT bound: max load <= mean + largest item
+        assert loads.max() <= loads.mean() + blocks.max()
+        assert (s == _lib.lpt_assign(lens, k)).all()  # deterministic
+    eq = _lib.lpt_assign(np.full(10000, 1 << 20, dtype=np.uint64), 8)
+    assert set(np.bincount(eq, minlength=8)) == {1250}

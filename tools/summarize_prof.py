@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_bench.sh output directory into tracked files under profiles/.
+
+usage: tools/summarize_prof.py gpurun_out/<dir> <tag>      (e.g. r01_wide_C2)
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim),
+profiles/<tag>_pmc.json (per-launch means of every counter for the sha512 kernel, with
+the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applied in `hbm_bytes_per_launch`)
+and profiles/traffic_<kernel>.json, which bench.py reads for roofline.traffic.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(out, tag + "_kernel_stats.csv"))
+pmc = {}
+kname = None
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "sha512" in r["Kernel_Name"]:
+                kname = "sha512_pair_kernel" if "pair" in r["Kernel_Name"] else "sha512_wide_kernel"
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                pmc.setdefault("_launch", {"grid": r["Grid_Size"], "workgroup": r["Workgroup_Size"],
+                                           "lds_bytes": r["LDS_Block_Size"], "vgpr": r["VGPR_Count"],
+                                           "agpr": r["Accum_VGPR_Count"], "sgpr": r["SGPR_Count"]})
+        for k, v in agg.items():
+            pmc[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+if "FETCH_SIZE" in pmc:
+    fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2   # KiB units; gfx950 reports half of a wide coalesced read
+    write = pmc.get("WRITE_SIZE", {"mean_per_launch": 0})["mean_per_launch"] * 1024
+    pmc["hbm_bytes_per_launch"] = fetch + write
+    pmc["_correction"] = "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reads 1/2 on gfx950)"
+    json.dump({"hbm_bytes_per_launch": fetch + write, "source": tag + "_pmc.json"},
+              open(os.path.join(out, "traffic_%s.json" % kname), "w"))
+json.dump(pmc, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+for name in ("bench_under_trace.log",):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        lines = [l for l in open(p, errors="replace") if l.startswith("{")]
+        if lines:
+            open(os.path.join(out, tag + "_bench_line.json"), "w").write(lines[-1])
+print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag) or f.startswith("traffic")))

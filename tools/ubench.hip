@@ -13,7 +13,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int kIters = 512;
+constexpr int kIters = 8192;
 
 // 16 instructions per loop body. IND: 8 independent destinations; DEP: one chain.
 #define BODY16(I) I(0) I(1) I(2) I(3) I(4) I(5) I(6) I(7) I(0) I(1) I(2) I(3) I(4) I(5) I(6) I(7)
@@ -29,8 +29,8 @@ constexpr int kIters = 512;
         SETUP                                                                                                \
         uint64_t t0 = __builtin_amdgcn_s_memtime();                                                          \
         for (int it = 0; it < kIters; ++it) {                                                                \
-            if (DEP) { asm volatile(BODY16(INSTR_DEP) : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : "v"(s0), "v"(s1), "v"(p0) : "vcc"); } \
-            else { asm volatile(BODY16(INSTR_IND) : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : "v"(s0), "v"(s1), "v"(p0) : "vcc"); } \
+            if (DEP) { asm volatile(BODY16(INSTR_DEP) : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : "v"(s0), "v"(s1), "v"(p0) : "vcc", "scc"); } \
+            else { asm volatile(BODY16(INSTR_IND) : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : "v"(s0), "v"(s1), "v"(p0) : "vcc", "scc"); } \
         }                                                                                                    \
         uint64_t t1 = __builtin_amdgcn_s_memtime();                                                          \
         if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;         \
@@ -163,6 +163,8 @@ static void run(const char* name, K kern, int instr_per_loop, int waves_per_simd
 
 int main()
 {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    printf("ubench start\n");
     uint64_t* d_cycles;
     uint32_t* d_sink;
     CHECK(hipMalloc(&d_cycles, 256 * 16 * 8 * 2));

@@ -154,6 +154,196 @@ __global__ __launch_bounds__(64) void sha512_wide_kernel(const Job* __restrict__
 }
 
 // ---------------------------------------------------------------------------
+// SPLIT kernel: for the stream-starved regime (fewer streams than the chip has
+// SIMDs x 64 lanes -- BASELINE config 2 has 10 001).  There a wave sits alone on
+// its SIMD and issues one VALU instruction per ~5 cycles whatever it does, so a
+// stream's speed is set by the instruction count of the wave that carries its
+// chaining value.  The 80 rounds need the chaining value; the message schedule
+// (W[16..79], 36 % of the work) does not.  So per 64 streams:
+//   wave 0      "round wave": only the 80 rounds, fed K[t]+W[t] from LDS
+//   waves 1, 2  "helper waves": fetch the 128-byte blocks (coalesced, staged in
+//               a wave-private LDS tile), byte-swap, pad, expand the schedule
+//               and store K[t]+W[t]; they take alternate blocks (wave 1 even,
+//               wave 2 odd) and have two block-times per block.
+// Hand-over through a ring of three 64x80-word K+W slots in LDS (row stride 81
+// words: conflict-free ds_read_b64 across streams), one workgroup barrier per
+// block-time.  One workgroup per CU (140 KB of LDS), each wave on its own SIMD.
+// ---------------------------------------------------------------------------
+constexpr int kKwRow = 81; // u64 per stream row of a K+W slot: 80 + 1 pad
+
+struct SplitShared {
+    uint64_t kw[3][64 * kKwRow];   // 3 x 41 472 B
+    uint4 tile[2][64 * kTileRow];  // one staging tile per helper wave
+    uint32_t maxblk;
+    uint32_t pad_[3];
+};
+
+__device__ __forceinline__ void load_kw16(uint64_t k[16], const uint64_t* __restrict__ row)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k[i] = row[i];
+}
+
+__device__ __forceinline__ void rounds16(uint64_t& a, uint64_t& b, uint64_t& c, uint64_t& d, uint64_t& e, uint64_t& f,
+                                         uint64_t& g, uint64_t& h, const uint64_t k[16])
+{
+    SNAPHASH_ROUND(a, b, c, d, e, f, g, h, k[0]);
+    SNAPHASH_ROUND(h, a, b, c, d, e, f, g, k[1]);
+    SNAPHASH_ROUND(g, h, a, b, c, d, e, f, k[2]);
+    SNAPHASH_ROUND(f, g, h, a, b, c, d, e, k[3]);
+    SNAPHASH_ROUND(e, f, g, h, a, b, c, d, k[4]);
+    SNAPHASH_ROUND(d, e, f, g, h, a, b, c, k[5]);
+    SNAPHASH_ROUND(c, d, e, f, g, h, a, b, k[6]);
+    SNAPHASH_ROUND(b, c, d, e, f, g, h, a, k[7]);
+    SNAPHASH_ROUND(a, b, c, d, e, f, g, h, k[8]);
+    SNAPHASH_ROUND(h, a, b, c, d, e, f, g, k[9]);
+    SNAPHASH_ROUND(g, h, a, b, c, d, e, f, k[10]);
+    SNAPHASH_ROUND(f, g, h, a, b, c, d, e, k[11]);
+    SNAPHASH_ROUND(e, f, g, h, a, b, c, d, k[12]);
+    SNAPHASH_ROUND(d, e, f, g, h, a, b, c, k[13]);
+    SNAPHASH_ROUND(c, d, e, f, g, h, a, b, k[14]);
+    SNAPHASH_ROUND(b, c, d, e, f, g, h, a, k[15]);
+}
+
+template <int T0, int T1>
+__device__ __forceinline__ void schedule_span(uint64_t w[16], uint64_t* __restrict__ row)
+{
+#pragma unroll
+    for (int t = T0; t < T1; ++t) {
+        if (t >= 16) w[t & 15] += small_sigma1(w[(t + 14) & 15]) + w[(t + 9) & 15] + small_sigma0(w[(t + 1) & 15]);
+        row[t] = w[t & 15] + K512[t];
+    }
+}
+
+__global__ __launch_bounds__(192) void sha512_split_kernel(const Job* __restrict__ jobs, uint32_t njobs,
+                                                           uint64_t* __restrict__ state,
+                                                           uint8_t* __restrict__ digests)
+{
+    __shared__ SplitShared sh;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // provably wave-uniform: scalar branches
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t slot = blockIdx.x * 64u + lane;
+    const bool have = slot < njobs;
+
+    Job jb;
+    if (have) {
+        jb = jobs[slot];
+    } else {
+        jb.data = 0; jb.nbytes = 0; jb.total_prev = 0; jb.idx = 0; jb.flags = 0;
+    }
+    const uint64_t nbytes = jb.nbytes;
+    const uint32_t nfull = (uint32_t)(nbytes >> 7);
+    const uint32_t rem = (uint32_t)(nbytes & 127);
+    const bool fin = (jb.flags & kJobFinal) != 0;
+    const uint32_t nblk = have ? padded_blocks(nbytes, fin) : 0u;
+    const uint64_t total = jb.total_prev + nbytes;
+
+    if (threadIdx.x == 0) sh.maxblk = 0;
+    __syncthreads();
+    if (wave == 0) atomicMax(&sh.maxblk, nblk);
+    __syncthreads();
+    const uint32_t steps = sh.maxblk + 2u; // every wave runs exactly `steps` barriers below
+
+    if (wave == 0) {
+        // ---------------- round wave ----------------
+        uint64_t H[8];
+        if (jb.flags & kJobFirst) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) H[k] = IV512[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) H[k] = have ? state[(uint64_t)jb.idx * 8 + k] : 0;
+        }
+        uint32_t ring = 0; // (tau - 2) % 3
+        for (uint32_t tau = 0; tau < steps; ++tau) {
+            __syncthreads();
+            if (tau < 2) continue;
+            const uint32_t b = tau - 2u;
+            const uint64_t* __restrict__ row = &sh.kw[ring][lane * kKwRow];
+            ring = (ring == 2u) ? 0u : ring + 1u;
+            // K+W arrives 16 rounds ahead of its use: two register sets, ping-pong
+            uint64_t a = H[0], bb = H[1], c = H[2], d = H[3], e = H[4], f = H[5], g = H[6], h = H[7];
+            uint64_t ka[16], kb[16];
+            load_kw16(ka, row);
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {
+                load_kw16(kb, row + 32 * i + 16);
+                rounds16(a, bb, c, d, e, f, g, h, ka);
+                load_kw16(ka, row + 32 * i + 32);
+                rounds16(a, bb, c, d, e, f, g, h, kb);
+            }
+            rounds16(a, bb, c, d, e, f, g, h, ka);
+            if (b < nblk) {
+                H[0] += a; H[1] += bb; H[2] += c; H[3] += d;
+                H[4] += e; H[5] += f; H[6] += g; H[7] += h;
+            }
+        }
+        if (have) {
+            if (fin) {
+                store_digest_be(digests + (uint64_t)jb.idx * 64, H);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) state[(uint64_t)jb.idx * 8 + k] = H[k];
+            }
+        }
+        return;
+    }
+
+    // ---------------- helper waves ----------------
+    const uint32_t hk = wave - 1u; // 0: even blocks, 1: odd blocks
+    uint4* __restrict__ tile = sh.tile[hk];
+    const uint32_t piece = lane & 7u;
+    const uint8_t* tptr[8];
+    uint32_t tnp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = 8 * i + (int)(lane >> 3);
+        const uint64_t dd = shfl_u64(jb.data, t);
+        const uint64_t nb = shfl_u64(nbytes, t);
+        tptr[i] = reinterpret_cast<const uint8_t*>(dd) + piece * 16u;
+        tnp[i] = (uint32_t)((nb + 15u) >> 4);
+    }
+    uint4 pre[8]; // block hk, then hk+2, ... (prefetched two block-times ahead of its use)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t p = hk * 8u + piece;
+        pre[i] = make_uint4(0, 0, 0, 0);
+        if (p < tnp[i]) pre[i] = load_u4(tptr[i] + (uint64_t)hk * 128u);
+    }
+    uint64_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = 0;
+    for (uint32_t tau = 0; tau < steps; ++tau) {
+        __syncthreads();
+        if ((tau & 1u) == hk) {
+            // first half of block tau: stage, swap, pad, words 0..39
+            const uint32_t b = tau;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tile[(8 * i + (lane >> 3)) * kTileRow + piece] = pre[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t p = (b + 2u) * 8u + piece;
+                pre[i] = make_uint4(0, 0, 0, 0);
+                if (p < tnp[i]) pre[i] = load_u4(tptr[i] + (uint64_t)(b + 2u) * 128u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint4 q = tile[lane * kTileRow + k];
+                w[2 * k] = be64(q.x, q.y);
+                w[2 * k + 1] = be64(q.z, q.w);
+            }
+            if (__any(b >= nfull && b < nblk)) apply_padding(w, b >= nfull, b - nfull, rem, total);
+            schedule_span<0, 40>(w, &sh.kw[b % 3u][lane * kKwRow]);
+        } else if (tau >= 1u) {
+            // second half of block tau-1: words 40..79
+            schedule_span<40, 80>(w, &sh.kw[(tau - 1u) % 3u][lane * kKwRow]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Synthetic content generator: file bytes = little-endian
 // SplitMix64 stream seeded 0x5eed000000000000 ^ file_index.  SplitMix64's state
 // is a plain counter, so word j of file i is mix(seed + (j+1)*gamma): fully
@@ -196,6 +386,14 @@ hipError_t launch_wide(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uin
     if (njobs == 0) return hipSuccess;
     const uint32_t grid = (njobs + 63u) / 64u;
     hipLaunchKernelGGL(sha512_wide_kernel, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
+    return hipGetLastError();
+}
+
+hipError_t launch_split(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s)
+{
+    if (njobs == 0) return hipSuccess;
+    const uint32_t grid = (njobs + 63u) / 64u;
+    hipLaunchKernelGGL(sha512_split_kernel, dim3(grid), dim3(192), 0, s, d_jobs, njobs, d_state, d_digests);
     return hipGetLastError();
 }
 

@@ -159,9 +159,16 @@ int ensure_slots(snaphash_ctx* c)
     return SNAPHASH_OK;
 }
 
-uint32_t pick_kernel(const snaphash_ctx* c, size_t /*nstreams*/)
+// SPLIT needs one workgroup (64 streams, 140 KB of LDS) per CU to be resident at
+// once and pays two block-times of pipeline fill, so it is for few, long streams;
+// beyond 256 CUs x 64 streams the lane-per-stream kernel fills the SIMDs by itself.
+constexpr size_t kSplitMaxStreams = 256 * 64;
+constexpr uint64_t kSplitMinMeanBlocks = 32;
+
+uint32_t pick_kernel(const snaphash_ctx* c, size_t nstreams, uint64_t blocks)
 {
-    if (c->kernel_pref == SNAPHASH_KERNEL_WIDE || c->kernel_pref == SNAPHASH_KERNEL_PAIR) return c->kernel_pref;
+    if (c->kernel_pref == SNAPHASH_KERNEL_WIDE || c->kernel_pref == SNAPHASH_KERNEL_SPLIT) return c->kernel_pref;
+    if (nstreams <= kSplitMaxStreams && blocks >= kSplitMinMeanBlocks * nstreams) return SNAPHASH_KERNEL_SPLIT;
     return SNAPHASH_KERNEL_WIDE;
 }
 
@@ -174,12 +181,15 @@ int launch_jobs(snaphash_ctx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_
     EventPair* ev = next_events(c, 0);
     if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
     HIP_TRY(c, hipEventRecord(ev->a, c->stream));
-    const uint32_t k = pick_kernel(c, n);
-    hipError_t e = launch_wide(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
+    uint64_t blocks = 0;
+    for (size_t i = 0; i < n; ++i) blocks += (h_jobs[i].nbytes >> 7) + 1;
+    const uint32_t k = pick_kernel(c, n, blocks);
+    hipError_t e = (k == SNAPHASH_KERNEL_SPLIT) ? launch_split(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream)
+                                                : launch_wide(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
     if (e != hipSuccess) return fail(c, SNAPHASH_EDEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
     HIP_TRY(c, hipEventRecord(ev->b, c->stream));
     c->stats.launches++;
-    c->stats.kernel_used = k == SNAPHASH_KERNEL_PAIR ? SNAPHASH_KERNEL_PAIR : SNAPHASH_KERNEL_WIDE;
+    c->stats.kernel_used = k;
     c->pending = true;
     return SNAPHASH_OK;
 }

@@ -87,12 +87,14 @@ def test_chunked_streaming_carries_state(built_lib, oracle):
     rng = np.random.default_rng(3)
     bufs = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
             for n in (1 << 20, (1 << 20) + 1, 300000, 65536, 128, 0, 5, 777777)]
-    with Context(staging_bytes=1 << 16) as small:  # 64 KiB staging -> many launches per file
-        got = small.sha512_buffers(bufs)
-        st = small.stats()
-    assert st["launches"] > 10
-    for b, d in zip(bufs, got):
-        assert d == oracle.sha512(b), len(b)
+    from snappy_amd import _lib
+    for kern in (_lib.KERNEL_WIDE, _lib.KERNEL_SPLIT):
+        with Context(staging_bytes=1 << 16, kernel=kern) as small:  # 64 KiB staging -> many launches per file
+            got = small.sha512_buffers(bufs)
+            st = small.stats()
+        assert st["launches"] > 10
+        for b, d in zip(bufs, got):
+            assert d == oracle.sha512(b), (kern, len(b))
 
 
 def test_files_entry_point_and_errors(ctx, oracle, tmp_path):

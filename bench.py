@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C5"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "split"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "split", "pair"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg (0 = skip)")
     return ap.parse_args()
 
@@ -123,7 +123,7 @@ def main():
     my_bytes = int(my_lens.sum())
     total_bytes = int(sizes.sum())
 
-    kern = {"auto": _lib.KERNEL_AUTO, "wide": _lib.KERNEL_WIDE, "split": _lib.KERNEL_SPLIT}[args.kernel]
+    kern = {"auto": _lib.KERNEL_AUTO, "wide": _lib.KERNEL_WIDE, "split": _lib.KERNEL_SPLIT, "pair": _lib.KERNEL_PAIR}[args.kernel]
     stream = torch.cuda.current_stream().cuda_stream
     ctx = Context(device=local_rank, kernel=kern, stream=stream)
     data = torch.empty(max(my_total, 16), dtype=torch.uint8, device="cuda")
@@ -180,9 +180,9 @@ def main():
         value = total_bytes / 2**30 / (elapsed / args.steps)
         k_ms = float(np.mean(kernel_ms))
         achieved = my_bytes / (k_ms * 1e-3) / 1e9
-        kname = "sha512_split_kernel" if st["kernel_used"] == _lib.KERNEL_SPLIT else "sha512_wide_kernel"
+        kname = {_lib.KERNEL_SPLIT: "sha512_split_kernel<false>", _lib.KERNEL_PAIR: "sha512_split_kernel<true>"}.get(st["kernel_used"], "sha512_wide_kernel")
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % kname)
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % kname.replace("<", "_").replace(">", ""))
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         line = {

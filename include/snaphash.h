@@ -54,8 +54,10 @@ enum {
 enum { /* snaphash_config.kernel */
     SNAPHASH_KERNEL_AUTO = 0, /* pick from the stream count and mean stream length */
     SNAPHASH_KERNEL_WIDE = 1, /* one lane per file stream does rounds + schedule (many-stream regime) */
-    SNAPHASH_KERNEL_SPLIT = 2 /* rounds on one wave, message schedule on helper waves, K+W through
-                                 an LDS ring (stream-starved regime: fewer streams than lanes) */
+    SNAPHASH_KERNEL_SPLIT = 2, /* rounds on one wave, message schedule on helper waves, K+W through
+                                  an LDS ring (stream-starved regime: fewer streams than lanes) */
+    SNAPHASH_KERNEL_PAIR = 3   /* SPLIT with every stream carried by a lane pair (e-chain / a-chain,
+                                  DPP exchange): fewest instructions on the critical wave */
 };
 
 typedef struct snaphash_ctx snaphash_ctx;
@@ -74,7 +76,7 @@ typedef struct snaphash_stats { /* of the most recent hashing call on the ctx */
     uint64_t blocks;        /* SHA-512 compression-function calls (incl. padding blocks) */
     uint64_t streams;       /* files/buffers hashed */
     uint32_t launches;      /* kernel launches issued */
-    uint32_t kernel_used;   /* SNAPHASH_KERNEL_WIDE or _SPLIT (last launch) */
+    uint32_t kernel_used;   /* SNAPHASH_KERNEL_WIDE, _SPLIT or _PAIR (last launch) */
     double kernel_ms;       /* sum over launches, HIP events on the launch stream */
     double h2d_ms;          /* host->HBM copies (files/buffers entry points) */
     double wall_ms;         /* whole call, host clock */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsnaphash.so")
 
 OK, EINVAL, ENOMEM, EIO, EDEVICE, EMODE, ENAME, EPARSE, EMISMATCH = 0, -1, -2, -3, -4, -5, -6, -7, -8
-KERNEL_AUTO, KERNEL_WIDE, KERNEL_SPLIT = 0, 1, 2
+KERNEL_AUTO, KERNEL_WIDE, KERNEL_SPLIT, KERNEL_PAIR = 0, 1, 2, 3
 
 # every symbol include/snaphash.h declares
 EXPORTS = [

@@ -21,6 +21,7 @@ struct Job {
 static_assert(sizeof(Job) == 32, "Job is 32 bytes");
 
 hipError_t launch_wide(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
+hipError_t launch_pair(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
 hipError_t launch_split(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
 hipError_t launch_fill_synthetic(uint8_t* d_base, const uint64_t* d_offsets, const uint64_t* d_lens,
                                  const uint64_t* d_findex, uint32_t nfiles, uint64_t max_len, hipStream_t s);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pair_rounds.inc"
 #include "sha512_core.h"
 #include "sha512_kernels.h"
 
@@ -215,11 +216,84 @@ __device__ __forceinline__ void schedule_span(uint64_t w[16], uint64_t* __restri
     }
 }
 
-__global__ __launch_bounds__(192) void sha512_split_kernel(const Job* __restrict__ jobs, uint32_t njobs,
-                                                           uint64_t* __restrict__ state,
-                                                           uint8_t* __restrict__ digests)
+// PAIR variant of the round wave(s): a stream is carried by a lane pair (role A:
+// e,f,g,h and T1; role B: a,b,c,d and T2) and the 80 rounds are the generated
+// assembly of pair_rounds.inc (tools/gen_pair_rounds.py): 24 instead of 32 VALU
+// instructions per round.  Two round waves of 32 streams each per workgroup.
+__device__ __forceinline__ void pair_round_wave(SplitShared& sh, uint32_t rw, uint32_t lane, const Job* __restrict__ jobs,
+                                                uint32_t njobs, uint32_t steps, uint64_t* __restrict__ state,
+                                                uint8_t* __restrict__ digests)
+{
+    const uint32_t j = lane & 7u;
+    const bool is_b = j >= 4u;
+    const uint32_t sl = 32u * rw + 4u * (lane >> 3) + (is_b ? 7u - j : j); // stream within the workgroup
+    const uint32_t slot = blockIdx.x * 64u + sl;
+    const bool have = slot < njobs;
+    Job jb;
+    if (have) {
+        jb = jobs[slot];
+    } else {
+        jb.data = 0; jb.nbytes = 0; jb.total_prev = 0; jb.idx = 0; jb.flags = 0;
+    }
+    const bool fin = (jb.flags & kJobFinal) != 0;
+    const uint32_t nblk = have ? padded_blocks(jb.nbytes, fin) : 0u;
+    const uint32_t half = is_b ? 0u : 4u; // B owns H[0..3] = a,b,c,d ; A owns H[4..7] = e,f,g,h
+    uint64_t Hx[4];
+    if (jb.flags & kJobFirst) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Hx[k] = is_b ? IV512[k] : IV512[4 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Hx[k] = have ? state[(uint64_t)jb.idx * 8 + half + k] : 0;
+    }
+    // per-lane rotate amounts: Sigma1(e) = rotr14(e ^ rotr4 e ^ rotr27 e), Sigma0(a) = rotr28(a ^ rotr6 a ^ rotr11 a)
+    const uint32_t c1 = is_b ? 6u : 4u, c2 = is_b ? 11u : 27u, c3 = is_b ? 28u : 14u;
+    const uint32_t mb = is_b ? 0xffffffffu : 0u;
+    uint32_t ring = 0;
+    for (uint32_t tau = 0; tau < steps; ++tau) {
+        __syncthreads();
+        if (tau < 2) continue;
+        const uint32_t b = tau - 2u;
+        const uint32_t addr =
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(const void*)&sh.kw[ring][sl * kKwRow];
+        ring = (ring == 2u) ? 0u : ring + 1u;
+        uint32_t x0l = lo32(Hx[0]), x0h = hi32(Hx[0]), x1l = lo32(Hx[1]), x1h = hi32(Hx[1]);
+        uint32_t x2l = lo32(Hx[2]), x2h = hi32(Hx[2]), x3l = lo32(Hx[3]), x3h = hi32(Hx[3]);
+        asm volatile(SNAPHASH_PAIR_ROUNDS_ASM
+                     : "+v"(x0l), "+v"(x0h), "+v"(x1l), "+v"(x1h), "+v"(x2l), "+v"(x2h), "+v"(x3l), "+v"(x3h)
+                     : "v"(c1), "v"(c2), "v"(c3), "v"(mb), "v"(addr)
+                     : SNAPHASH_PAIR_CLOBBERS, "memory");
+        if (b < nblk) {
+            Hx[0] += mk64(x0l, x0h); Hx[1] += mk64(x1l, x1h);
+            Hx[2] += mk64(x2l, x2h); Hx[3] += mk64(x3l, x3h);
+        }
+    }
+    if (have) {
+        if (fin) {
+            uint4* o = reinterpret_cast<uint4*>(digests + (uint64_t)jb.idx * 64 + half * 8);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                uint4 v;
+                v.x = __builtin_bswap32(hi32(Hx[2 * k]));
+                v.y = __builtin_bswap32(lo32(Hx[2 * k]));
+                v.z = __builtin_bswap32(hi32(Hx[2 * k + 1]));
+                v.w = __builtin_bswap32(lo32(Hx[2 * k + 1]));
+                o[k] = v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) state[(uint64_t)jb.idx * 8 + half + k] = Hx[k];
+        }
+    }
+}
+
+template <bool PAIR>
+__global__ __launch_bounds__(PAIR ? 256 : 192) void sha512_split_kernel(const Job* __restrict__ jobs, uint32_t njobs,
+                                                                        uint64_t* __restrict__ state,
+                                                                        uint8_t* __restrict__ digests)
 {
     __shared__ SplitShared sh;
+    constexpr uint32_t kRoundWaves = PAIR ? 2u : 1u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // provably wave-uniform: scalar branches
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t slot = blockIdx.x * 64u + lane;
@@ -240,11 +314,15 @@ __global__ __launch_bounds__(192) void sha512_split_kernel(const Job* __restrict
 
     if (threadIdx.x == 0) sh.maxblk = 0;
     __syncthreads();
-    if (wave == 0) atomicMax(&sh.maxblk, nblk);
+    if (wave == kRoundWaves) atomicMax(&sh.maxblk, nblk); // first helper wave: lane = stream
     __syncthreads();
     const uint32_t steps = sh.maxblk + 2u; // every wave runs exactly `steps` barriers below
 
-    if (wave == 0) {
+    if (PAIR && wave < kRoundWaves) {
+        pair_round_wave(sh, wave, lane, jobs, njobs, steps, state, digests);
+        return;
+    }
+    if (!PAIR && wave == 0) {
         // ---------------- round wave ----------------
         uint64_t H[8];
         if (jb.flags & kJobFirst) {
@@ -290,7 +368,7 @@ __global__ __launch_bounds__(192) void sha512_split_kernel(const Job* __restrict
     }
 
     // ---------------- helper waves ----------------
-    const uint32_t hk = wave - 1u; // 0: even blocks, 1: odd blocks
+    const uint32_t hk = wave - kRoundWaves; // 0: even blocks, 1: odd blocks
     uint4* __restrict__ tile = sh.tile[hk];
     const uint32_t piece = lane & 7u;
     const uint8_t* tptr[8];
@@ -393,7 +471,15 @@ hipError_t launch_split(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, ui
 {
     if (njobs == 0) return hipSuccess;
     const uint32_t grid = (njobs + 63u) / 64u;
-    hipLaunchKernelGGL(sha512_split_kernel, dim3(grid), dim3(192), 0, s, d_jobs, njobs, d_state, d_digests);
+    hipLaunchKernelGGL(sha512_split_kernel<false>, dim3(grid), dim3(192), 0, s, d_jobs, njobs, d_state, d_digests);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s)
+{
+    if (njobs == 0) return hipSuccess;
+    const uint32_t grid = (njobs + 63u) / 64u;
+    hipLaunchKernelGGL(sha512_split_kernel<true>, dim3(grid), dim3(256), 0, s, d_jobs, njobs, d_state, d_digests);
     return hipGetLastError();
 }
 

@@ -167,8 +167,10 @@ constexpr uint64_t kSplitMinMeanBlocks = 32;
 
 uint32_t pick_kernel(const snaphash_ctx* c, size_t nstreams, uint64_t blocks)
 {
-    if (c->kernel_pref == SNAPHASH_KERNEL_WIDE || c->kernel_pref == SNAPHASH_KERNEL_SPLIT) return c->kernel_pref;
-    if (nstreams <= kSplitMaxStreams && blocks >= kSplitMinMeanBlocks * nstreams) return SNAPHASH_KERNEL_SPLIT;
+    if (c->kernel_pref == SNAPHASH_KERNEL_WIDE || c->kernel_pref == SNAPHASH_KERNEL_SPLIT ||
+        c->kernel_pref == SNAPHASH_KERNEL_PAIR)
+        return c->kernel_pref;
+    if (nstreams <= kSplitMaxStreams && blocks >= kSplitMinMeanBlocks * nstreams) return SNAPHASH_KERNEL_PAIR;
     return SNAPHASH_KERNEL_WIDE;
 }
 
@@ -184,8 +186,9 @@ int launch_jobs(snaphash_ctx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_
     uint64_t blocks = 0;
     for (size_t i = 0; i < n; ++i) blocks += (h_jobs[i].nbytes >> 7) + 1;
     const uint32_t k = pick_kernel(c, n, blocks);
-    hipError_t e = (k == SNAPHASH_KERNEL_SPLIT) ? launch_split(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream)
-                                                : launch_wide(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
+    hipError_t e = (k == SNAPHASH_KERNEL_PAIR)    ? launch_pair(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream)
+                   : (k == SNAPHASH_KERNEL_SPLIT) ? launch_split(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream)
+                                                  : launch_wide(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
     if (e != hipSuccess) return fail(c, SNAPHASH_EDEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
     HIP_TRY(c, hipEventRecord(ev->b, c->stream));
     c->stats.launches++;

@@ -88,7 +88,7 @@ def test_chunked_streaming_carries_state(built_lib, oracle):
     bufs = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
             for n in (1 << 20, (1 << 20) + 1, 300000, 65536, 128, 0, 5, 777777)]
     from snappy_amd import _lib
-    for kern in (_lib.KERNEL_WIDE, _lib.KERNEL_SPLIT):
+    for kern in (_lib.KERNEL_WIDE, _lib.KERNEL_SPLIT, _lib.KERNEL_PAIR):
         with Context(staging_bytes=1 << 16, kernel=kern) as small:  # 64 KiB staging -> many launches per file
             got = small.sha512_buffers(bufs)
             st = small.stats()

@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Generator (and lane-level simulator) of the PAIR round block: the 80 SHA-512
+rounds of one 128-byte block with every stream carried by a lane PAIR.
+
+Why: in the stream-starved regime a wave issues ~5 cycles per instruction
+whatever it does, so a stream's speed is the instruction count of the wave
+holding its chaining value.  Splitting a stream over two
+lanes of the same wave -- lane A owns (e,f,g,h) and computes T1, lane B owns
+(a,b,c,d) and computes T2 -- lets ONE instruction serve Sigma1(e) in the A lanes
+and Sigma0(a) in the B lanes (per-lane rotate amounts in a VGPR), and likewise
+Ch/Maj and the adds: 24 instructions per round instead of 32.
+
+Lane layout (64 lanes = 32 streams): in every group of 8 lanes, lanes 0-3 are
+role A of four streams and lanes 4-7 role B of the same streams mirrored, so
+the partner of a lane is DPP row_half_mirror and DPP bank_mask 0x5 / 0xA writes
+only A / only B lanes.
+
+The same instruction list is (a) printed as gfx950 assembly into
+snappy_amd/csrc/pair_rounds.inc (physical VGPRs, used inside one inline-asm
+statement by sha512_kernels.hip) and (b) executed by `simulate()` on 64 numpy
+lanes, which tests/test_pair_sim.py checks against a plain SHA-512 -- the data
+flow is proven on the CPU before it ever runs on the GPU.
+
+  python3 tools/gen_pair_rounds.py          # rewrites pair_rounds.inc
+"""
+import os
+
+import numpy as np
+
+M32 = 0xFFFFFFFF
+BASE = 64  # first physical VGPR of the block; the kernel lists v64..v97 as clobbers
+
+# ---- register map -----------------------------------------------------------------
+REG = {}
+def _alloc():
+    n = BASE
+    for name in ("R0", "R1", "R2", "R3"):          # the four rotating state pairs
+        REG[name + "l"], REG[name + "h"] = n, n + 1
+        n += 2
+    for name in ("C1", "C2", "C3", "MB", "ADDR", "spare"):  # per-lane constants
+        REG[name] = n
+        n += 1
+    for name in ("T", "U", "S", "M", "BF", "VV", "TT", "V2", "KW0", "KW1"):  # aligned pairs
+        REG[name + "l"], REG[name + "h"] = n, n + 1
+        n += 2
+    return n
+LAST = _alloc() - 1
+assert BASE % 2 == 0 and LAST == 97
+
+IN_ORDER = ["R0l", "R0h", "R1l", "R1h", "R2l", "R2h", "R3l", "R3h", "C1", "C2", "C3", "MB", "ADDR"]
+A_BANKS, B_BANKS = 0x5, 0xA
+
+
+def build(rounds=80):
+    """-> list of instruction tuples for one block."""
+    ins = []
+    e = ins.append
+    e(("waitcnt", 0))
+    e(("ds_read_b64", "KW0", "ADDR", 0))
+    for i in range(rounds):
+        x = ["R%d" % ((k - i) % 4) for k in range(4)]  # x0..x3 of this round
+        kw, kwn = "KW%d" % (i & 1), "KW%d" % ((i + 1) & 1)
+        if i + 1 < rounds:
+            e(("ds_read_b64", kwn, "ADDR", 8 * (i + 1)))
+        # S = rotr(x0 ^ rotr(x0,c1) ^ rotr(x0,c2), c3)   [A: Sigma1(e) c=(4,27,14); B: Sigma0(a) c=(6,11,28)]
+        e(("alignbit", "Tl", x[0] + "h", x[0] + "l", "C1"))
+        e(("alignbit", "Th", x[0] + "l", x[0] + "h", "C1"))
+        e(("alignbit", "Ul", x[0] + "h", x[0] + "l", "C2"))
+        e(("alignbit", "Uh", x[0] + "l", x[0] + "h", "C2"))
+        e(("xor", "Tl", "Tl", "Ul"))
+        e(("xor", "Th", "Th", "Uh"))
+        e(("xor", "Tl", "Tl", x[0] + "l"))
+        e(("xor", "Th", "Th", x[0] + "h"))
+        e(("alignbit", "Sl", "Th", "Tl", "C3"))
+        e(("alignbit", "Sh", "Tl", "Th", "C3"))
+        # M = x0 ^ (x2 & MB)   [A: e ; B: a ^ c];  BF = bfi(M, x1, x2)   [A: Ch(e,f,g) ; B: Maj(a,b,c)]
+        e(("and", "Ml", x[2] + "l", "MB"))
+        e(("and", "Mh", x[2] + "h", "MB"))
+        e(("xor", "Ml", "Ml", x[0] + "l"))
+        e(("xor", "Mh", "Mh", x[0] + "h"))
+        e(("bfi", "BFl", "Ml", x[1] + "l", x[2] + "l"))
+        e(("bfi", "BFh", "Mh", x[1] + "h", x[2] + "h"))
+        e(("add64", "VV", "S", "BF"))            # A: Sigma1+Ch ; B: T2 = Sigma0+Maj
+        e(("waitcnt", 1 if i + 1 < rounds else 0))
+        e(("add64", "TT", x[3], kw))             # A: h + (K+W) ; B: unused
+        e(("add64", "V2", "VV", "TT"))           # A: T1 ; B: unused
+        # x3 <- new chain value (x0 of the next round)
+        e(("add_co_dpp", x[3] + "l", x[3] + "l", "V2l", A_BANKS))    # A: e' = d(partner) + T1
+        e(("addc_co_dpp", x[3] + "h", x[3] + "h", "V2h", A_BANKS))
+        e(("add_co_dpp", x[3] + "l", "V2l", "VVl", B_BANKS))         # B: a' = T1(partner) + T2
+        e(("addc_co_dpp", x[3] + "h", "V2h", "VVh", B_BANKS))
+    return ins
+
+
+# ---- assembly printer ----------------------------------------------------------------
+def v(name):
+    return "v%d" % REG[name]
+
+def vp(name):
+    return "v[%d:%d]" % (REG[name + "l"], REG[name + "h"])
+
+def to_asm(ins):
+    out = []
+    for t in ins:
+        op = t[0]
+        if op == "waitcnt":
+            out.append("s_waitcnt lgkmcnt(%d)" % t[1])
+        elif op == "ds_read_b64":
+            out.append("ds_read_b64 %s, %s offset:%d" % (vp(t[1]), v(t[2]), t[3]))
+        elif op == "alignbit":
+            out.append("v_alignbit_b32 %s, %s, %s, %s" % (v(t[1]), v(t[2]), v(t[3]), v(t[4])))
+        elif op == "xor":
+            out.append("v_xor_b32 %s, %s, %s" % (v(t[1]), v(t[2]), v(t[3])))
+        elif op == "and":
+            out.append("v_and_b32 %s, %s, %s" % (v(t[1]), v(t[2]), v(t[3])))
+        elif op == "bfi":
+            out.append("v_bfi_b32 %s, %s, %s, %s" % (v(t[1]), v(t[2]), v(t[3]), v(t[4])))
+        elif op == "add64":
+            out.append("v_lshl_add_u64 %s, %s, 0, %s" % (vp(t[1]), vp(t[2]), vp(t[3])))
+        elif op == "add_co_dpp":
+            out.append("v_add_co_u32_dpp %s, vcc, %s, %s row_half_mirror row_mask:0xf bank_mask:0x%x" %
+                       (v(t[1]), v(t[2]), v(t[3]), t[4]))
+        elif op == "addc_co_dpp":
+            out.append("v_addc_co_u32_dpp %s, vcc, %s, %s, vcc row_half_mirror row_mask:0xf bank_mask:0x%x" %
+                       (v(t[1]), v(t[2]), v(t[3]), t[4]))
+        else:
+            raise ValueError(op)
+    return out
+
+
+def write_inc(path):
+    ins = build()
+    body = to_asm(ins)
+    n_valu = sum(1 for t in ins if t[0] not in ("waitcnt", "ds_read_b64"))
+    lines = ["// GENERATED by tools/gen_pair_rounds.py -- do not edit.",
+             "// One 128-byte block = 80 SHA-512 rounds on lane pairs; %d VALU + %d LDS reads." %
+             (n_valu, sum(1 for t in ins if t[0] == "ds_read_b64")),
+             "// Physical registers v%d..v%d (clobbered); operands %%0..%%7 = state halves (in/out)," % (BASE, LAST),
+             "// %8..%10 = per-lane rotate amounts, %11 = role mask (B: ~0, A: 0), %12 = LDS byte address of the K+W row.",
+             "#define SNAPHASH_PAIR_FIRST_VGPR %d" % BASE,
+             "#define SNAPHASH_PAIR_LAST_VGPR %d" % LAST,
+             "#define SNAPHASH_PAIR_ROUNDS_ASM \\"]
+    for k, name in enumerate(IN_ORDER):
+        lines.append('    "v_mov_b32 %s, %%%d\\n" \\' % (v(name), k))
+    for s in body:
+        lines.append('    "%s\\n" \\' % s)
+    for k, name in enumerate(IN_ORDER[:8]):
+        lines.append('    "v_mov_b32 %%%d, %s\\n" \\' % (k, v(name)))
+    lines.append('    ""')
+    clob = ", ".join('"v%d"' % n for n in range(BASE, LAST + 1))
+    lines.append("#define SNAPHASH_PAIR_CLOBBERS %s, \"vcc\"" % clob)
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return len(body)
+
+
+# ---- lane-level simulator ----------------------------------------------------------------
+def partner_index():
+    lane = np.arange(64)
+    return (lane & ~7) | (7 - (lane & 7))
+
+def bank_enable(mask):
+    lane = np.arange(64)
+    return ((mask >> ((lane & 15) >> 2)) & 1).astype(bool)
+
+def simulate(ins, regs, lds):
+    """regs: dict name -> np.uint32[64] (keys of REG); lds: np.uint8 array (byte addressed).
+    Executes the list in order (the hardware issues one wave in order, so program order is
+    the semantics; s_waitcnt only has to be placed before the first use, which is asserted)."""
+    P = partner_index()
+    pending = []  # outstanding ds_read destinations, in issue order
+    vcc = np.zeros(64, dtype=np.uint64)
+    def g(n):
+        for p in pending:
+            assert n not in p, "read of %s before its ds_read was waited for" % n
+        return regs[n]
+    def g64(pair):
+        return g(pair + "l").astype(np.uint64) | (g(pair + "h").astype(np.uint64) << np.uint64(32))
+    for t in ins:
+        op = t[0]
+        if op == "waitcnt":
+            while len(pending) > t[1]:
+                pending.pop(0)
+        elif op == "ds_read_b64":
+            addr = g(t[2]).astype(np.int64) + t[3]
+            lo = np.zeros(64, dtype=np.uint32)
+            hi = np.zeros(64, dtype=np.uint32)
+            for l in range(64):
+                b = lds[addr[l]:addr[l] + 8]
+                lo[l] = int.from_bytes(bytes(b[:4]), "little")
+                hi[l] = int.from_bytes(bytes(b[4:]), "little")
+            regs[t[1] + "l"], regs[t[1] + "h"] = lo, hi
+            pending.append((t[1] + "l", t[1] + "h"))
+        elif op == "alignbit":
+            hi, lo, sh = g(t[2]).astype(np.uint64), g(t[3]).astype(np.uint64), (g(t[4]) & 31).astype(np.uint64)
+            regs[t[1]] = ((((hi << np.uint64(32)) | lo) >> sh) & np.uint64(M32)).astype(np.uint32)
+        elif op == "xor":
+            regs[t[1]] = g(t[2]) ^ g(t[3])
+        elif op == "and":
+            regs[t[1]] = g(t[2]) & g(t[3])
+        elif op == "bfi":
+            m = g(t[2])
+            regs[t[1]] = (m & g(t[3])) | (~m & g(t[4]))
+        elif op == "add64":
+            with np.errstate(over="ignore"):
+                r = g64(t[2]) + g64(t[3])
+            regs[t[1] + "l"] = (r & np.uint64(M32)).astype(np.uint32)
+            regs[t[1] + "h"] = (r >> np.uint64(32)).astype(np.uint32)
+        elif op in ("add_co_dpp", "addc_co_dpp"):
+            en = bank_enable(t[4])
+            s = g(t[2])[P].astype(np.uint64) + g(t[3]).astype(np.uint64)
+            if op == "addc_co_dpp":
+                s = s + vcc
+            old = regs[t[1]]
+            regs[t[1]] = np.where(en, (s & np.uint64(M32)).astype(np.uint32), old)
+            vcc = np.where(en, s >> np.uint64(32), vcc)   # only enabled lanes are relied upon
+        else:
+            raise ValueError(op)
+    assert not pending, "block ends with LDS reads in flight"
+    return regs
+
+
+def lane_roles():
+    """-> (role_is_B[64], local_stream[64]) of the round wave's lane layout."""
+    lane = np.arange(64)
+    j = lane & 7
+    is_b = j >= 4
+    stream = 4 * (lane >> 3) + np.where(is_b, 7 - j, j)
+    return is_b, stream
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(os.path.dirname(here), "snappy_amd", "csrc", "pair_rounds.inc")
+    n = write_inc(out)
+    print("wrote %s: %d instructions per block (%.2f per round)" % (out, n, n / 80.0))

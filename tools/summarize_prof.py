@@ -29,7 +29,8 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "sha512" in r["Kernel_Name"]:
-                kname = "sha512_split_kernel" if "split" in r["Kernel_Name"] else "sha512_wide_kernel"
+                kn = r["Kernel_Name"]
+                kname = ("sha512_split_kernel_true" if "<true>" in kn or "ILb1" in kn else "sha512_split_kernel_false") if "split" in kn else "sha512_wide_kernel"
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 pmc.setdefault("_launch", {"grid": r["Grid_Size"], "workgroup": r["Workgroup_Size"],
                                            "lds_bytes": r["LDS_Block_Size"], "vgpr": r["VGPR_Count"],

@@ -72,7 +72,7 @@ def run_block(rounds, seed):
 
 
 def test_pair_rounds_match_sha512():
-    for rounds, seed in ((1, 1), (2, 2), (3, 3), (4, 4), (7, 5), (80, 6), (80, 7)):
+    for rounds, seed in ((2, 2), (4, 4), (6, 5), (80, 6), (80, 7)):
         run_block(rounds, seed)
 
 
@@ -93,7 +93,7 @@ def test_generated_inc_is_current():
         fresh = os.path.join(tmp, "x.inc")
         n = gp.write_inc(fresh)
         assert open(fresh).read() == open(path).read()
-    assert n == 2 + 80 * 25 - 1  # per round: 24 VALU/LDS + 1 waitcnt (no prefetch in the last round)
+    assert n == 2 + 80 * 23 + 39 + 40  # per round 23 VALU; per two rounds one ds_read2_b64 and one s_waitcnt
 
 
 def test_dpp_hazard_distance():
@@ -104,5 +104,5 @@ def test_dpp_hazard_distance():
             src = t[2]
             for back in (1, 2):
                 p = ins[i - back]
-                written = {p[1]} if p[0] not in ("add64", "ds_read_b64") else {p[1] + "l", p[1] + "h"}
+                written = {p[1]} if p[0] not in ("add64", "ds_read2_b64") else {p[1] + "l", p[1] + "h"}
                 assert src not in written, (i, t, p)

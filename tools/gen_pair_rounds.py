@@ -40,12 +40,12 @@ def _alloc():
     for name in ("C1", "C2", "C3", "MB", "ADDR", "spare"):  # per-lane constants
         REG[name] = n
         n += 1
-    for name in ("T", "U", "S", "M", "BF", "VV", "TT", "V2", "KW0", "KW1"):  # aligned pairs
+    for name in ("T", "U", "S", "M", "BF", "VV", "TT", "V2", "KW0", "KW1", "KW2", "KW3"):  # aligned pairs
         REG[name + "l"], REG[name + "h"] = n, n + 1
         n += 2
     return n
 LAST = _alloc() - 1
-assert BASE % 2 == 0 and LAST == 97
+assert BASE % 2 == 0 and LAST == 101
 
 IN_ORDER = ["R0l", "R0h", "R1l", "R1h", "R2l", "R2h", "R3l", "R3h", "C1", "C2", "C3", "MB", "ADDR"]
 A_BANKS, B_BANKS = 0x5, 0xA
@@ -56,12 +56,15 @@ def build(rounds=80):
     ins = []
     e = ins.append
     e(("waitcnt", 0))
-    e(("ds_read_b64", "KW0", "ADDR", 0))
+    # K+W arrives two rounds per LDS instruction, two rounds ahead of its first use:
+    # register sets (KW0,KW1) and (KW2,KW3) alternate every two rounds
+    e(("ds_read2_b64", "KW0", "ADDR", 0))
     for i in range(rounds):
         x = ["R%d" % ((k - i) % 4) for k in range(4)]  # x0..x3 of this round
-        kw, kwn = "KW%d" % (i & 1), "KW%d" % ((i + 1) & 1)
-        if i + 1 < rounds:
-            e(("ds_read_b64", kwn, "ADDR", 8 * (i + 1)))
+        kw = "KW%d" % (i & 3)
+        more = (i & 1) == 0 and i + 2 < rounds
+        if more:
+            e(("ds_read2_b64", "KW%d" % ((i + 2) & 3), "ADDR", i + 2))
         # S = rotr(x0 ^ rotr(x0,c1) ^ rotr(x0,c2), c3)   [A: Sigma1(e) c=(4,27,14); B: Sigma0(a) c=(6,11,28)]
         e(("alignbit", "Tl", x[0] + "h", x[0] + "l", "C1"))
         e(("alignbit", "Th", x[0] + "l", x[0] + "h", "C1"))
@@ -81,7 +84,8 @@ def build(rounds=80):
         e(("bfi", "BFl", "Ml", x[1] + "l", x[2] + "l"))
         e(("bfi", "BFh", "Mh", x[1] + "h", x[2] + "h"))
         e(("add64", "VV", "S", "BF"))            # A: Sigma1+Ch ; B: T2 = Sigma0+Maj
-        e(("waitcnt", 1 if i + 1 < rounds else 0))
+        if (i & 1) == 0:
+            e(("waitcnt", 1 if more else 0))
         e(("add64", "TT", x[3], kw))             # A: h + (K+W) ; B: unused
         e(("add64", "V2", "VV", "TT"))           # A: T1 ; B: unused
         # x3 <- new chain value (x0 of the next round)
@@ -105,8 +109,9 @@ def to_asm(ins):
         op = t[0]
         if op == "waitcnt":
             out.append("s_waitcnt lgkmcnt(%d)" % t[1])
-        elif op == "ds_read_b64":
-            out.append("ds_read_b64 %s, %s offset:%d" % (vp(t[1]), v(t[2]), t[3]))
+        elif op == "ds_read2_b64":  # two u64 at ADDR + 8*t[3] and ADDR + 8*(t[3]+1) into 4 consecutive VGPRs
+            out.append("ds_read2_b64 v[%d:%d], %s offset0:%d offset1:%d" %
+                       (REG[t[1] + "l"], REG[t[1] + "l"] + 3, v(t[2]), t[3], t[3] + 1))
         elif op == "alignbit":
             out.append("v_alignbit_b32 %s, %s, %s, %s" % (v(t[1]), v(t[2]), v(t[3]), v(t[4])))
         elif op == "xor":
@@ -131,10 +136,10 @@ def to_asm(ins):
 def write_inc(path):
     ins = build()
     body = to_asm(ins)
-    n_valu = sum(1 for t in ins if t[0] not in ("waitcnt", "ds_read_b64"))
+    n_valu = sum(1 for t in ins if t[0] not in ("waitcnt", "ds_read2_b64"))
     lines = ["// GENERATED by tools/gen_pair_rounds.py -- do not edit.",
              "// One 128-byte block = 80 SHA-512 rounds on lane pairs; %d VALU + %d LDS reads." %
-             (n_valu, sum(1 for t in ins if t[0] == "ds_read_b64")),
+             (n_valu, sum(1 for t in ins if t[0] == "ds_read2_b64")),
              "// Physical registers v%d..v%d (clobbered); operands %%0..%%7 = state halves (in/out)," % (BASE, LAST),
              "// %8..%10 = per-lane rotate amounts, %11 = role mask (B: ~0, A: 0), %12 = LDS byte address of the K+W row.",
              "#define SNAPHASH_PAIR_FIRST_VGPR %d" % BASE,
@@ -181,16 +186,19 @@ def simulate(ins, regs, lds):
         if op == "waitcnt":
             while len(pending) > t[1]:
                 pending.pop(0)
-        elif op == "ds_read_b64":
-            addr = g(t[2]).astype(np.int64) + t[3]
-            lo = np.zeros(64, dtype=np.uint32)
-            hi = np.zeros(64, dtype=np.uint32)
+        elif op == "ds_read2_b64":
+            first = REG[t[1] + "l"]
+            names = [n for n, r in sorted(REG.items(), key=lambda kv: kv[1]) if first <= r < first + 4]
+            assert len(names) == 4 and first % 2 == 0
+            addr = g(t[2]).astype(np.int64) + 8 * t[3]
+            vals = [np.zeros(64, dtype=np.uint32) for _ in range(4)]
             for l in range(64):
-                b = lds[addr[l]:addr[l] + 8]
-                lo[l] = int.from_bytes(bytes(b[:4]), "little")
-                hi[l] = int.from_bytes(bytes(b[4:]), "little")
-            regs[t[1] + "l"], regs[t[1] + "h"] = lo, hi
-            pending.append((t[1] + "l", t[1] + "h"))
+                b = bytes(lds[addr[l]:addr[l] + 16])
+                for q in range(4):
+                    vals[q][l] = int.from_bytes(b[4 * q:4 * q + 4], "little")
+            for n, val in zip(names, vals):
+                regs[n] = val
+            pending.append(tuple(names))
         elif op == "alignbit":
             hi, lo, sh = g(t[2]).astype(np.uint64), g(t[3]).astype(np.uint64), (g(t[4]) & 31).astype(np.uint64)
             regs[t[1]] = ((((hi << np.uint64(32)) | lo) >> sh) & np.uint64(M32)).astype(np.uint32)

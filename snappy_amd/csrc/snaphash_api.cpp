@@ -42,7 +42,8 @@ struct Slot {
     Job* h_jobs = nullptr;    // pinned
     Job* d_jobs = nullptr;
     size_t jobs_cap = 0;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;   // kernel of the batch staged in this slot has finished
+    hipEvent_t copied = nullptr; // H2D of this slot's data + jobs has finished
     bool busy = false;
 };
 
@@ -58,6 +59,7 @@ struct snaphash_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t copy_stream = nullptr; // H2D of batch k+1 overlaps the kernel of batch k
     uint64_t staging = kDefaultStaging;
     uint32_t kernel_pref = SNAPHASH_KERNEL_AUTO;
 
@@ -155,44 +157,84 @@ int ensure_slots(snaphash_ctx* c)
         if (!s.h_buf) HIP_TRY(c, hipHostMalloc((void**)&s.h_buf, c->staging, hipHostMallocDefault));
         if (!s.d_buf) HIP_TRY(c, hipMalloc((void**)&s.d_buf, c->staging));
         if (!s.done) HIP_TRY(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        if (!s.copied) HIP_TRY(c, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
     }
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     return SNAPHASH_OK;
 }
 
-// SPLIT needs one workgroup (64 streams, 140 KB of LDS) per CU to be resident at
-// once and pays two block-times of pipeline fill, so it is for few, long streams;
-// beyond 256 CUs x 64 streams the lane-per-stream kernel fills the SIMDs by itself.
+// Kernel choice.  PAIR/SPLIT need one workgroup (64 streams, 140 KB of LDS) per CU
+// resident at once and pay two block-times of pipeline fill, so they are for few,
+// long streams; beyond 256 CUs x 64 streams the lane-per-stream kernel fills the
+// SIMDs by itself.  A heavy-tailed batch (BASELINE config 5: Zipf sizes) is cut in
+// two: the long head goes to PAIR (per-stream latency decides the makespan), the
+// short tail to WIDE.
 constexpr size_t kSplitMaxStreams = 256 * 64;
-constexpr uint64_t kSplitMinMeanBlocks = 32;
+constexpr uint64_t kSplitMinBlocks = 32;
 
-uint32_t pick_kernel(const snaphash_ctx* c, size_t nstreams, uint64_t blocks)
+uint64_t job_blocks(const Job& j) { return (j.nbytes >> 7) + 1; }
+
+hipError_t launch_kernel(uint32_t k, const Job* d_jobs, size_t n, snaphash_ctx* c, uint8_t* d_digests)
 {
-    if (c->kernel_pref == SNAPHASH_KERNEL_WIDE || c->kernel_pref == SNAPHASH_KERNEL_SPLIT ||
-        c->kernel_pref == SNAPHASH_KERNEL_PAIR)
-        return c->kernel_pref;
-    if (nstreams <= kSplitMaxStreams && blocks >= kSplitMinMeanBlocks * nstreams) return SNAPHASH_KERNEL_PAIR;
-    return SNAPHASH_KERNEL_WIDE;
+    if (k == SNAPHASH_KERNEL_PAIR) return launch_pair(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
+    if (k == SNAPHASH_KERNEL_SPLIT) return launch_split(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
+    return launch_wide(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
 }
 
-// Sort (longest first, so the 64 lanes of a wave finish together), upload and launch.
-int launch_jobs(snaphash_ctx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_digests)
+// h_jobs is sorted longest first.  Returns how many leading jobs go to the
+// few-long-streams kernel (*k_head) and which kernel takes the rest (*k_tail).
+size_t plan_kernels(const snaphash_ctx* c, const Job* h_jobs, size_t n, uint32_t* k_head, uint32_t* k_tail)
+{
+    *k_tail = SNAPHASH_KERNEL_WIDE;
+    if (c->kernel_pref == SNAPHASH_KERNEL_WIDE || c->kernel_pref == SNAPHASH_KERNEL_SPLIT ||
+        c->kernel_pref == SNAPHASH_KERNEL_PAIR) {
+        *k_head = c->kernel_pref;
+        return n;
+    }
+    *k_head = SNAPHASH_KERNEL_PAIR;
+    uint64_t blocks = 0;
+    for (size_t i = 0; i < n; ++i) blocks += job_blocks(h_jobs[i]);
+    if (n <= kSplitMaxStreams) {
+        if (blocks >= kSplitMinBlocks * n) return n; // few, long streams
+        *k_head = SNAPHASH_KERNEL_WIDE;
+        return n;
+    }
+    // many streams: all WIDE unless the head dwarfs the rest
+    if (job_blocks(h_jobs[0]) >= 8 * job_blocks(h_jobs[kSplitMaxStreams - 1]) &&
+        job_blocks(h_jobs[0]) >= kSplitMinBlocks) {
+        size_t head = 0;
+        while (head < kSplitMaxStreams && job_blocks(h_jobs[head]) >= kSplitMinBlocks) ++head;
+        return head;
+    }
+    *k_head = SNAPHASH_KERNEL_WIDE;
+    return n;
+}
+
+// Sort (longest first, so the lanes of a wave finish together), upload and launch.
+// When `copied` is given, the job array goes up on the copy stream and the kernel waits
+// for that event (the staging engine); otherwise everything is on the launch stream.
+int launch_jobs(snaphash_ctx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_digests, hipEvent_t copied = nullptr)
 {
     if (n == 0) return SNAPHASH_OK;
     std::stable_sort(h_jobs, h_jobs + n, [](const Job& a, const Job& b) { return a.nbytes > b.nbytes; });
-    HIP_TRY(c, hipMemcpyAsync(d_jobs, h_jobs, n * sizeof(Job), hipMemcpyHostToDevice, c->stream));
+    if (copied) {
+        HIP_TRY(c, hipMemcpyAsync(d_jobs, h_jobs, n * sizeof(Job), hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(copied, c->copy_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, copied, 0));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(d_jobs, h_jobs, n * sizeof(Job), hipMemcpyHostToDevice, c->stream));
+    }
+    uint32_t k_head, k_tail;
+    const size_t head = plan_kernels(c, h_jobs, n, &k_head, &k_tail);
     EventPair* ev = next_events(c, 0);
     if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
     HIP_TRY(c, hipEventRecord(ev->a, c->stream));
-    uint64_t blocks = 0;
-    for (size_t i = 0; i < n; ++i) blocks += (h_jobs[i].nbytes >> 7) + 1;
-    const uint32_t k = pick_kernel(c, n, blocks);
-    hipError_t e = (k == SNAPHASH_KERNEL_PAIR)    ? launch_pair(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream)
-                   : (k == SNAPHASH_KERNEL_SPLIT) ? launch_split(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream)
-                                                  : launch_wide(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
+    hipError_t e = launch_kernel(k_head, d_jobs, head, c, d_digests);
+    if (e == hipSuccess && head < n) e = launch_kernel(k_tail, d_jobs + head, n - head, c, d_digests);
     if (e != hipSuccess) return fail(c, SNAPHASH_EDEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
     HIP_TRY(c, hipEventRecord(ev->b, c->stream));
-    c->stats.launches++;
-    c->stats.kernel_used = k;
+    c->stats.launches += (head < n) ? 2 : 1;
+    c->stats.kernel_used = k_head;
     c->pending = true;
     return SNAPHASH_OK;
 }
@@ -200,6 +242,7 @@ int launch_jobs(snaphash_ctx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_
 int sync_ctx(snaphash_ctx* c)
 {
     if (!c->pending && c->ev_used == 0) return SNAPHASH_OK;
+    if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     collect_events(c);
     c->pending = false;
@@ -318,14 +361,14 @@ int hash_sources(snaphash_ctx* c, const std::vector<Source>& src, uint8_t* diges
         run_reads(src, ops, first_err, first_err_src);
         if (first_err.load()) break;
 
-        if (used) {
+        if (used) { // copy stream: the slot's previous kernel was already waited for above
             EventPair* ev = next_events(c, 1);
             if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
-            HIP_TRY(c, hipEventRecord(ev->a, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, used, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+            HIP_TRY(c, hipEventRecord(ev->a, c->copy_stream));
+            HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, used, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(c, hipEventRecord(ev->b, c->copy_stream));
         }
-        rc = launch_jobs(c, sl.h_jobs, sl.d_jobs, nj, c->d_digests);
+        rc = launch_jobs(c, sl.h_jobs, sl.d_jobs, nj, c->d_digests, sl.copied);
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(sl.done, c->stream));
         sl.busy = true;
@@ -422,7 +465,9 @@ void snaphash_destroy(snaphash_ctx* c)
         if (s.h_jobs) (void)hipHostFree(s.h_jobs);
         if (s.d_jobs) (void)hipFree(s.d_jobs);
         if (s.done) (void)hipEventDestroy(s.done);
+        if (s.copied) (void)hipEventDestroy(s.copied);
     }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_state) (void)hipFree(c->d_state);

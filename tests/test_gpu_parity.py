@@ -220,3 +220,43 @@ def test_config_c2_full_size_properties(ctx, oracle):
     ctx.sync()
     assert (out2.cpu().numpy() == got[perm]).all()
     assert hashlib.sha512(got.tobytes()).hexdigest() == hashlib.sha512(out2.cpu().numpy()[np.argsort(perm)].tobytes()).hexdigest()
+
+
+def test_config_c5_zipf_scaled_vs_oracle(built_lib, oracle):
+    """BASELINE config 5 (Zipf-mixed sizes) scaled to 20 000 files / ~2.7 GiB: every digest
+    bit-exact against the oracle; with AUTO the batch is cut into a long head (PAIR kernel)
+    and a short tail (WIDE kernel)."""
+    torch = _torch()
+    from snappy_amd import Context, synthetic
+    lens = np.minimum(synthetic.zipf_sizes(20000), np.uint64(1 << 25))  # cap the head at 32 MiB: keeps the run in seconds
+    off, total = synthetic.pack_offsets(lens)
+    idx = np.arange(len(lens), dtype=np.uint64)
+    with Context() as c:
+        dev = torch.empty(total, dtype=torch.uint8, device="cuda")
+        c.fill_synthetic_device(dev.data_ptr(), off, lens, idx)
+        out = torch.zeros((len(lens), 64), dtype=torch.uint8, device="cuda")
+        c.sha512_device(dev.data_ptr(), off, lens, out.data_ptr())
+        c.sync()
+        st = c.stats()
+        got = out.cpu().numpy()
+        host = dev.cpu().numpy()
+    assert st["launches"] == 2  # head + tail
+    want = oracle.sha512_batch(host, off, lens)
+    assert (got == want).all()
+
+
+def test_config_c3_large_file_streaming(built_lib, oracle):
+    """BASELINE config 3 (large-file streaming through chunked staging), scaled: 6 x 192 MiB
+    host buffers through 2 x 64 MiB staging buffers -- each file crosses many launches with
+    its chaining value carried in HBM.  Checked bit-exact against the oracle."""
+    from snappy_amd import Context
+    rng = np.random.default_rng(9)
+    n = 192 << 20
+    base = rng.integers(0, 256, size=n + 4096, dtype=np.uint8)
+    bufs = [base[k * 131: k * 131 + n - k].tobytes() for k in range(6)]  # ragged lengths, different phases
+    with Context(staging_bytes=64 << 20) as c:
+        got = c.sha512_buffers(bufs)
+        st = c.stats()
+    assert st["launches"] >= 18 and st["bytes_hashed"] == sum(len(b) for b in bufs)
+    for b, d in zip(bufs, got):
+        assert d == oracle.sha512(b)

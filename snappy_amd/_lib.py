@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnaphash.so")
+# SNAPHASH_LIB: developer override to A/B another build of the same ABI (tools/ab_bench.sh)
+LIB_PATH = os.environ.get("SNAPHASH_LIB") or os.path.join(_HERE, "libsnaphash.so")
 
 OK, EINVAL, ENOMEM, EIO, EDEVICE, EMODE, ENAME, EPARSE, EMISMATCH = 0, -1, -2, -3, -4, -5, -6, -7, -8
 KERNEL_AUTO, KERNEL_WIDE, KERNEL_SPLIT, KERNEL_PAIR = 0, 1, 2, 3

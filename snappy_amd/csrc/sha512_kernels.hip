@@ -250,6 +250,7 @@ __device__ __forceinline__ void pair_round_wave(SplitShared& sh, uint32_t rw, ui
     const uint32_t c1 = is_b ? 6u : 4u, c2 = is_b ? 11u : 27u, c3 = is_b ? 28u : 14u;
     const uint32_t mb = is_b ? 0xffffffffu : 0u;
     uint32_t ring = 0;
+    __builtin_amdgcn_s_setprio(3); // the chaining-value wave is the critical path: win every arbitration on the CU
     for (uint32_t tau = 0; tau < steps; ++tau) {
         __syncthreads();
         if (tau < 2) continue;
@@ -259,8 +260,10 @@ __device__ __forceinline__ void pair_round_wave(SplitShared& sh, uint32_t rw, ui
         ring = (ring == 2u) ? 0u : ring + 1u;
         uint32_t x0l = lo32(Hx[0]), x0h = hi32(Hx[0]), x1l = lo32(Hx[1]), x1h = hi32(Hx[1]);
         uint32_t x2l = lo32(Hx[2]), x2h = hi32(Hx[2]), x3l = lo32(Hx[3]), x3h = hi32(Hx[3]);
+        uint32_t loop_counter; // scratch SGPR of the generated block
         asm volatile(SNAPHASH_PAIR_ROUNDS_ASM
-                     : "+v"(x0l), "+v"(x0h), "+v"(x1l), "+v"(x1h), "+v"(x2l), "+v"(x2h), "+v"(x3l), "+v"(x3h)
+                     : "+v"(x0l), "+v"(x0h), "+v"(x1l), "+v"(x1h), "+v"(x2l), "+v"(x2h), "+v"(x3l), "+v"(x3h),
+                       "=&s"(loop_counter)
                      : "v"(c1), "v"(c2), "v"(c3), "v"(mb), "v"(addr)
                      : SNAPHASH_PAIR_CLOBBERS, "memory");
         if (b < nblk) {
@@ -333,6 +336,7 @@ __global__ __launch_bounds__(PAIR ? 256 : 192) void sha512_split_kernel(const Jo
             for (int k = 0; k < 8; ++k) H[k] = have ? state[(uint64_t)jb.idx * 8 + k] : 0;
         }
         uint32_t ring = 0; // (tau - 2) % 3
+        __builtin_amdgcn_s_setprio(3); // critical path of every stream in the workgroup
         for (uint32_t tau = 0; tau < steps; ++tau) {
             __syncthreads();
             if (tau < 2) continue;

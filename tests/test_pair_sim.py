@@ -33,7 +33,7 @@ def ref_rounds(state, kw):
     return [a, b, c, d, e, f, g, h]
 
 
-def run_block(rounds, seed):
+def run_block(rounds, seed, loop_rounds=0):
     rng = np.random.default_rng(seed)
     is_b, stream = gp.lane_roles()
     assert sorted(stream.tolist()) == sorted(list(range(32)) * 2)
@@ -60,7 +60,7 @@ def run_block(rounds, seed):
         regs["C1"][lane], regs["C2"][lane], regs["C3"][lane] = c
         regs["MB"][lane] = 0xFFFFFFFF if is_b[lane] else 0
         regs["ADDR"][lane] = base + stream[lane] * row_bytes
-    out = gp.simulate(gp.build(rounds), regs, lds)
+    out = gp.simulate(gp.build(rounds, loop_rounds), regs, lds)
     for lane in range(64):
         want = ref_rounds(states[stream[lane]], kws[stream[lane]])
         want = want[0:4] if is_b[lane] else want[4:8]
@@ -74,6 +74,8 @@ def run_block(rounds, seed):
 def test_pair_rounds_match_sha512():
     for rounds, seed in ((2, 2), (4, 4), (6, 5), (80, 6), (80, 7)):
         run_block(rounds, seed)
+    for loop_rounds, seed in ((4, 8), (8, 9), (16, 10), (gp.LOOP_ROUNDS, 11)):
+        run_block(80, seed, loop_rounds)  # hardware-loop forms, incl. the shipped one
 
 
 def test_sigma_decomposition():
@@ -93,12 +95,16 @@ def test_generated_inc_is_current():
         fresh = os.path.join(tmp, "x.inc")
         n = gp.write_inc(fresh)
         assert open(fresh).read() == open(path).read()
-    assert n == 2 + 80 * 23 + 39 + 40  # per round 23 VALU; per two rounds one ds_read2_b64 and one s_waitcnt
+    if gp.LOOP_ROUNDS:
+        L = gp.LOOP_ROUNDS  # body: L rounds of 23 VALU, L/2 (ds_read2_b64 + s_waitcnt); + loop control
+        assert n == 2 + 2 + L * 23 + L + 1 + 3 + 1
+    else:
+        assert n == 2 + 80 * 23 + 39 + 40  # per round 23 VALU; per two rounds one ds_read2_b64 and one s_waitcnt
 
 
 def test_dpp_hazard_distance():
     """gfx9: a VGPR written by VALU must not be read through DPP by either of the next two instructions."""
-    ins = [t for t in gp.build() if t[0] != "waitcnt"]
+    ins = [t for t in gp.build(loop_rounds=0) if t[0] != "waitcnt"]
     for i, t in enumerate(ins):
         if t[0] in ("add_co_dpp", "addc_co_dpp"):
             src = t[2]

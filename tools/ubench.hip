@@ -136,8 +136,9 @@ __global__ __launch_bounds__(1024) void k_lds_mix(uint64_t* cycles, uint32_t* si
 template <typename K>
 static void run(const char* name, K kern, int instr_per_loop, int waves_per_simd, uint64_t* d_cycles, uint32_t* d_sink)
 {
-    // one workgroup per CU, 4*waves_per_simd waves each
-    const int threads = 256 * waves_per_simd;
+    // one workgroup per CU, 4*waves_per_simd waves each; waves_per_simd < 0 means -waves_per_simd
+    // waves per CU in total (1 or 2: fewer waves than SIMDs)
+    const int threads = waves_per_simd > 0 ? 256 * waves_per_simd : 64 * -waves_per_simd;
     const int blocks = 256;
     const int nw = blocks * threads / 64;
     CHECK(hipMemset(d_cycles, 0, nw * 8));
@@ -172,7 +173,7 @@ int main()
     hipDeviceProp_t p;
     CHECK(hipGetDeviceProperties(&p, 0));
     printf("device %s CUs=%d clock=%d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
-    for (int w : {1, 2, 4}) {
+    for (int w : {-1, -2, 1, 2, 4}) {
 #define RUN(k, n) run(#k " ind", k<false>, n, w, d_cycles, d_sink); run(#k " dep", k<true>, n, w, d_cycles, d_sink)
         RUN(k_alignbit, 16);
         RUN(k_xor, 16);

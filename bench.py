@@ -106,7 +106,9 @@ def main():
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # SNAPHASH_BENCH_FORCE_DIST=1: run the RCCL path even with one rank (rehearsal on a 1-GPU box)
+    force_dist = os.environ.get("SNAPHASH_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -135,14 +137,14 @@ def main():
 
     def step(record):
         ctx.sha512_device(data.data_ptr(), my_off, my_lens, local.data_ptr())
-        full = gather_digests(local, plan)  # RCCL all-gather of the digest slabs (no-op at N = 1)
+        full = gather_digests(local, plan, force_collective=force_dist)  # RCCL all-gather of the digest slabs (no-op at N = 1)
         ctx.sync()
         if record:
             kernel_ms.append(ctx.stats()["kernel_ms"])
         return full
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -186,7 +188,8 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         line = {
-            "metric": "GiB/s hashed (whole node), bit-exact hashes.yaml, 10k x 1 MiB tree",
+            "metric": "GiB/s hashed (whole node), bit-exact hashes.yaml, 10k x 1 MiB tree" if args.workload == "C2"
+                      else "GiB/s hashed (whole node), bit-exact hashes.yaml, workload %s" % args.workload,
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -207,7 +210,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(tree, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -33,13 +33,13 @@ class ShardPlan:
         return self._members[rank]
 
 
-def gather_digests(local_slab, plan, group=None):
+def gather_digests(local_slab, plan, group=None, force_collective=False):
     """local_slab: uint8 tensor [kmax, 64] (rows beyond this rank's count are
     ignored).  Returns the full [n_files, 64] digest matrix in walk order on every
     rank.  Works on CUDA tensors over RCCL and on CPU tensors over gloo."""
     import torch
     import torch.distributed as dist
-    if plan.world == 1:
+    if plan.world == 1 and not force_collective:
         return local_slab[:len(plan.sizes)]
     gathered = torch.empty((plan.world * plan.kmax, 64), dtype=torch.uint8, device=local_slab.device)
     dist.all_gather_into_tensor(gathered.view(-1), local_slab.contiguous().view(-1), group=group)

@@ -260,3 +260,22 @@ def test_config_c3_large_file_streaming(built_lib, oracle):
     assert st["launches"] >= 18 and st["bytes_hashed"] == sum(len(b) for b in bufs)
     for b, d in zip(bufs, got):
         assert d == oracle.sha512(b)
+
+
+def test_cli_tree_and_verify(built_lib, tmp_path):
+    """snappy_amd/bin/snaphash (plain C over include/snaphash.h): the golden tree through the CLI."""
+    import subprocess
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "snappy_amd", "bin", "snaphash")
+    assert os.path.exists(cli), "build with make -C snappy_amd/csrc"
+    build, tar = trees.make_simple_tree(str(tmp_path))
+    want = open(os.path.join(GOLDEN, "hashes_simple.yaml"), "rb").read()
+    got = subprocess.run([cli, "tree", build, tar], stdout=subprocess.PIPE, check=True, timeout=120).stdout
+    assert got == want
+    y = tmp_path / "hashes.yaml"
+    y.write_bytes(got)
+    assert subprocess.run([cli, "verify", build, str(y), tar], timeout=120).returncode == 0
+    open(os.path.join(build, "bin", "bar"), "ab").write(b"tampered")
+    assert subprocess.run([cli, "verify", build, str(y), tar], stderr=subprocess.DEVNULL, timeout=120).returncode == 1
+    out = subprocess.run([cli, "hash", tar], stdout=subprocess.PIPE, check=True, timeout=120).stdout.decode()
+    assert out.startswith("cf83e1357eefb8bd") and out.rstrip().endswith(tar)

@@ -279,3 +279,28 @@ def test_cli_tree_and_verify(built_lib, tmp_path):
     assert subprocess.run([cli, "verify", build, str(y), tar], stderr=subprocess.DEVNULL, timeout=120).returncode == 1
     out = subprocess.run([cli, "hash", tar], stdout=subprocess.PIPE, check=True, timeout=120).stdout.decode()
     assert out.startswith("cf83e1357eefb8bd") and out.rstrip().endswith(tar)
+
+
+def test_config_c2_on_disk_tree_scaled(built_lib, oracle):
+    """BASELINE config 2 as a real on-disk tree (scaled to 1 500 x 1 MiB to keep the oracle in seconds;
+    the full 10 000-file run is tools/e2e_tree.py, result in profiles/r01_e2e_tree_C2_full.txt):
+    snaphash_tree's hashes.yaml byte-identical to the oracle's."""
+    import shutil
+    import tempfile
+    from snappy_amd import Context, synthetic
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(prefix="snaphash_c2_", dir=base)
+    try:
+        build = os.path.join(tmp, "build")
+        for i in range(1500):
+            p = os.path.join(build, synthetic.file_name(i))
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            oracle.fill_synthetic(1 << 20, i).tofile(p)
+        tar = os.path.join(tmp, "data.tar.gz")
+        oracle.fill_synthetic(1 << 20, 1500).tofile(tar)
+        with Context() as c:
+            got = c.tree(build, tar)
+        assert got == oracle.hashes_yaml(build, tar)
+        assert got.count(b"- name: ") == 1500 + 15
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

@@ -102,7 +102,7 @@ int snaphash_sha512_buffers(snaphash_ctx *ctx, const void *const *bufs, const ui
 
 /* Same, for content already resident in HBM: file i is the byte range
  * [d_base+offsets[i], +lens[i]).  offsets/lens are host arrays; every offset and
- * d_base must be 16-byte aligned.  d_digests is device memory, n*64 bytes.
+ * d_base must be 16-byte aligned, every length < 32 GiB.  d_digests is device memory, n*64 bytes.
  * Enqueues on the ctx stream and returns; snaphash_sync waits for completion.
  * This is the kernel-resident (roofline) entry point. */
 int snaphash_sha512_device(snaphash_ctx *ctx, const void *d_base, const uint64_t *offsets,

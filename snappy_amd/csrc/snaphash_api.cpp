@@ -524,6 +524,7 @@ int snaphash_sha512_device(snaphash_ctx* c, const void* d_base, const uint64_t* 
     if (rc) return rc;
     for (size_t i = 0; i < n; ++i) {
         if (offsets[i] & 15) return fail(c, SNAPHASH_EINVAL, "offsets must be 16-byte aligned");
+        if (lens[i] >> 35) return fail(c, SNAPHASH_EINVAL, "a resident stream is limited to 32 GiB per call (32-bit block counters)");
         Job& j = c->h_jobs[i];
         j.data = (uint64_t)(uintptr_t)d_base + offsets[i];
         j.nbytes = lens[i];

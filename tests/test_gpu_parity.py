@@ -304,3 +304,23 @@ def test_config_c2_on_disk_tree_scaled(built_lib, oracle):
         assert got.count(b"- name: ") == 1500 + 15
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_device_entry_point_argument_checks(built_lib):
+    torch = _torch()
+    from snappy_amd import Context, SnaphashError, _lib
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    out = torch.zeros((2, 64), dtype=torch.uint8, device="cuda")
+    with Context() as c:
+        for off, ln in (([8, 0], [16, 16]), ([0, 16], [1 << 35, 16])):  # misaligned offset; oversize stream
+            with pytest.raises(SnaphashError) as e:
+                c.sha512_device(buf.data_ptr(), np.array(off, dtype=np.uint64), np.array(ln, dtype=np.uint64), out.data_ptr())
+            assert e.value.code == _lib.EINVAL
+        with pytest.raises(SnaphashError):
+            c.sha512_device(buf.data_ptr() + 4, np.array([0], dtype=np.uint64), np.array([16], dtype=np.uint64), out.data_ptr())
+        # and the context is still usable afterwards
+        c.sha512_device(buf.data_ptr(), np.array([0, 16], dtype=np.uint64), np.array([16, 0], dtype=np.uint64), out.data_ptr())
+        c.sync()
+    import hashlib
+    assert out[0].cpu().numpy().tobytes() == hashlib.sha512(b"\0" * 16).digest()
+    assert out[1].cpu().numpy().tobytes() == hashlib.sha512(b"").digest()

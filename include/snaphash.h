@@ -161,6 +161,16 @@ void snaphash_records_free(snaphash_records *r);
 int snaphash_emit_yaml(const snaphash_records *r, const uint8_t archive_digest[64],
                        const uint8_t *file_digests, char **yaml_out, size_t *yaml_len);
 
+/* yaml.Unmarshal into hashesYaml (the reader side, snappy/snapp.go:466-478): parses the
+ * yaml.v2 rendering of the schema -- plain, 'single' and "double" quoted scalars, the
+ * empty document {} (common_test.go:77-80), files: [] -- into a record set (path is "",
+ * st_mode carries type + permission bits).  archive_hex (may be NULL) receives
+ * archive-sha512 as written, NUL-terminated, at most 128 characters. */
+int snaphash_parse_yaml(const char *yaml, size_t yaml_len, snaphash_records **out, char archive_hex[129]);
+/* sha512 hexdigest text of record i of a parsed set ("" for directories, symlinks and
+ * for record sets that come from snaphash_walk). */
+const char *snaphash_records_sha512_hex(const snaphash_records *r, size_t i);
+
 /* yamlFileMode.MarshalYAML / UnmarshalYAML (hashes.go:33-88).  out: 11 bytes.
  * mode_parse yields a POSIX st_mode (S_IFDIR/S_IFLNK/S_IFREG | perm bits) and
  * rejects the empty string instead of indexing it. */

@@ -21,7 +21,7 @@ EXPORTS = [
     "snaphash_sha512_files", "snaphash_sha512_buffers", "snaphash_sha512_device", "snaphash_sync",
     "snaphash_tree", "snaphash_write_hashes", "snaphash_verify", "snaphash_free",
     "snaphash_walk", "snaphash_records_count", "snaphash_records_get", "snaphash_records_free",
-    "snaphash_emit_yaml", "snaphash_mode_string", "snaphash_mode_parse", "snaphash_lpt_assign",
+    "snaphash_emit_yaml", "snaphash_parse_yaml", "snaphash_records_sha512_hex", "snaphash_mode_string", "snaphash_mode_parse", "snaphash_lpt_assign",
     "snaphash_fill_synthetic_device", "snaphash_strerror", "snaphash_last_error", "snaphash_get_stats",
 ]
 
@@ -84,6 +84,9 @@ def lib():
     L.snaphash_records_free.argtypes = [vp]
     L.snaphash_records_free.restype = None
     L.snaphash_emit_yaml.argtypes = [vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.snaphash_parse_yaml.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.c_char_p]
+    L.snaphash_records_sha512_hex.argtypes = [vp, sz]
+    L.snaphash_records_sha512_hex.restype = ctypes.c_char_p
     L.snaphash_mode_string.argtypes = [ctypes.c_uint32, ctypes.c_char_p]
     L.snaphash_mode_parse.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)]
     L.snaphash_lpt_assign.argtypes = [vp, sz, ctypes.c_int, vp]
@@ -237,6 +240,26 @@ def emit_yaml(build_dir, archive_digest, file_digests):
             return ctypes.string_at(p.value, n.value)
         finally:
             lib().snaphash_free(p)
+    finally:
+        lib().snaphash_records_free(h)
+
+
+def parse_yaml(text):
+    """yaml.Unmarshal into hashesYaml -> (archive_hex, [record dicts])."""
+    h = ctypes.c_void_p()
+    arch = ctypes.create_string_buffer(129)
+    rc = lib().snaphash_parse_yaml(text, len(text), ctypes.byref(h), arch)
+    if rc:
+        raise SnaphashError(rc)
+    try:
+        out = []
+        r = Record()
+        for i in range(lib().snaphash_records_count(h)):
+            lib().snaphash_records_get(h, i, ctypes.byref(r))
+            out.append({"name": r.name.decode(errors="surrogateescape"), "st_mode": r.st_mode,
+                        "is_regular": bool(r.is_regular), "size": r.size,
+                        "sha512": lib().snaphash_records_sha512_hex(h, i).decode()})
+        return arch.value.decode(), out
     finally:
         lib().snaphash_records_free(h)
 

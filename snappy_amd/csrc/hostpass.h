@@ -16,6 +16,7 @@ struct Record {          // one fileHash (snappy/hashes.go:93-101) before hashin
     uint32_t st_mode = 0;
     bool is_regular = false;
     int64_t size = 0;
+    std::string sha512_hex; // only for records parsed from a hashes.yaml
 };
 
 struct ParsedRecord {

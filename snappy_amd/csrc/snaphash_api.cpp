@@ -717,6 +717,33 @@ int snaphash_records_get(const snaphash_records* r, size_t i, snaphash_record* o
 }
 void snaphash_records_free(snaphash_records* r) { delete r; }
 
+int snaphash_parse_yaml(const char* yaml, size_t yaml_len, snaphash_records** out, char archive_hex[129])
+{
+    if (!yaml || !out) return SNAPHASH_EINVAL;
+    ParsedHashes ph;
+    int rc = parse_yaml(yaml, yaml_len, ph);
+    if (rc) return rc;
+    snaphash_records* r = new (std::nothrow) snaphash_records();
+    if (!r) return SNAPHASH_ENOMEM;
+    for (const ParsedRecord& p : ph.files) {
+        Record x;
+        x.name = p.name;
+        x.st_mode = p.st_mode;
+        x.is_regular = S_ISREG(p.st_mode);
+        x.size = p.has_size ? p.size : 0;
+        x.sha512_hex = p.sha512_hex;
+        r->v.push_back(std::move(x));
+    }
+    if (archive_hex) snprintf(archive_hex, 129, "%s", ph.archive_hex.c_str());
+    *out = r;
+    return SNAPHASH_OK;
+}
+
+const char* snaphash_records_sha512_hex(const snaphash_records* r, size_t i)
+{
+    return (r && i < r->v.size()) ? r->v[i].sha512_hex.c_str() : "";
+}
+
 int snaphash_emit_yaml(const snaphash_records* r, const uint8_t archive_digest[64], const uint8_t* file_digests,
                        char** yaml_out, size_t* yaml_len)
 {

@@ -149,3 +149,55 @@ def test_lpt_assign(built_lib):
         assert (s == _lib.lpt_assign(lens, k)).all()  # deterministic
     eq = _lib.lpt_assign(np.full(10000, 1 << 20, dtype=np.uint64), 8)
     assert set(np.bincount(eq, minlength=8)) == {1250}
+
+
+def test_emitted_yaml_is_valid_yaml_for_the_reader_side(built_lib, oracle, tmp_path):
+    """Row a8: whatever we emit must unmarshal into hashesYaml{ArchiveSha512, Files[]fileHash}
+    (snappy/snapp.go:466-478 reads archive-sha512 back).  PyYAML stands in for yaml.v2's parser."""
+    import yaml
+    from snappy_amd import _lib
+    build, tar = trees.make_synthetic_tree(str(tmp_path), [5, 0, 300, 70000, 12])
+    recs = _lib.walk(build)
+    digs = [oracle.sha512(open(r["path"], "rb").read()) for r in recs if r["is_regular"]]
+    arch = oracle.sha512(open(tar, "rb").read())
+    doc = yaml.safe_load(_lib.emit_yaml(build, arch, digs))
+    assert set(doc) == {"archive-sha512", "files"} and doc["archive-sha512"] == arch.hex()
+    assert [f["name"] for f in doc["files"]] == [r["name"] for r in recs]
+    k = 0
+    for f, r in zip(doc["files"], recs):
+        assert list(f)[0] == "name" and list(f)[-1] == "mode"        # key order name,size,sha512,mode
+        assert _lib.mode_parse(f["mode"]) & 0o777 == r["st_mode"] & 0o777
+        if r["is_regular"]:
+            assert f["size"] == r["size"] and f["sha512"] == digs[k].hex()
+            k += 1
+        else:
+            assert "size" not in f and "sha512" not in f
+
+
+def test_parse_yaml_reader_side(built_lib):
+    """The parser behind snaphash_verify: yaml.v2's renderings of hashesYaml, CPU only."""
+    from snappy_amd import _lib, SnaphashError
+    golden = open(os.path.join(GOLDEN, "hashes_simple.yaml"), "rb").read()
+    arch, recs = _lib.parse_yaml(golden)
+    assert arch.startswith("cf83e135") and len(arch) == 128
+    assert [r["name"] for r in recs] == ["bin", "bin/bar", "broken-link", "foo"]
+    assert [r["is_regular"] for r in recs] == [False, True, False, True]
+    assert recs[1]["size"] == 4 and recs[1]["sha512"].startswith("cc06808c") and recs[3]["size"] == 0
+    assert stat.S_ISDIR(recs[0]["st_mode"]) and stat.S_ISLNK(recs[2]["st_mode"]) and recs[2]["st_mode"] & 0o777 == 0o777
+    # snappy/hashes_test.go:30-33 as a one-record list; quoted scalars as yaml.v2 writes odd names; xattr ignored
+    text = (b"archive-sha512: F00F00\nfiles:\n- name: \"123\"\n  size: 10\n  mode: drw-r--r--\n"
+            b"- name: 'it''s'\n  mode: frw-r--r--\n  size: 0\n  sha512: abc\n  xattr:\n    user.k: v\n"
+            b"- name: \"tab\\there \\u00e9\"\n  mode: lrwxrwxrwx\n")
+    arch, recs = _lib.parse_yaml(text)
+    assert arch == "F00F00"  # snappy/snapp_test.go:159-170 TestLocalSnapHash: carried as a string
+    assert [r["name"] for r in recs] == ["123", "it's", "tab\there \u00e9"]
+    assert recs[0]["size"] == 10 and stat.S_ISDIR(recs[0]["st_mode"]) and recs[0]["st_mode"] & 0o777 == 0o644
+    assert recs[1]["sha512"] == "abc" and recs[1]["is_regular"]
+    assert _lib.parse_yaml(b"{}\n") == ("", [])                       # snappy/common_test.go:77-80
+    assert _lib.parse_yaml(b"archive-sha512: ab\nfiles: []\n") == ("ab", [])
+    for bad in (b"files:\n- name: x\n", b"files:\n- mode: frw-r--r--\n", b"files:\n- name: x\n  mode: ''\n",
+                b"files:\n- name: x\n  mode: qrw-r--r--\n", b"files:\n- name: x\n  size: ten\n  mode: frw-r--r--\n",
+                b"- name: x\n", b"files: 3\n"):
+        with pytest.raises(SnaphashError) as e:
+            _lib.parse_yaml(bad)
+        assert e.value.code == _lib.EPARSE, bad

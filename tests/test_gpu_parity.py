@@ -324,3 +324,27 @@ def test_device_entry_point_argument_checks(built_lib):
     import hashlib
     assert out[0].cpu().numpy().tobytes() == hashlib.sha512(b"\0" * 16).digest()
     assert out[1].cpu().numpy().tobytes() == hashlib.sha512(b"").digest()
+
+
+def test_randomized_ragged_batches_all_kernels(built_lib):
+    """Stress: random batch shapes (empty, tiny, block-boundary and multi-hundred-KB streams mixed),
+    random staging sizes (so streams cross launch boundaries at random 128-byte multiples), every
+    kernel variant, both host entry points -- all digests against hashlib.sha512."""
+    import hashlib
+    from snappy_amd import Context, _lib
+    rng = np.random.default_rng(2024)
+    blob = rng.integers(0, 256, size=3 << 20, dtype=np.uint8).tobytes()
+    special = [0, 1, 111, 112, 113, 127, 128, 129, 239, 240, 255, 256, 257, 1023, 1024, 4095, 4096, 65535, 65536]
+    for it in range(12):
+        n = int(rng.integers(1, 400))
+        lens = [int(x) for x in np.where(rng.random(n) < 0.3, rng.choice(special, size=n),
+                                         rng.integers(0, int(rng.choice([300, 5000, 300000])), size=n))]
+        offs = [int(rng.integers(0, len(blob) - l + 1)) for l in lens]
+        bufs = [blob[o:o + l] for o, l in zip(offs, lens)]
+        want = [hashlib.sha512(b).digest() for b in bufs]
+        kern = [_lib.KERNEL_WIDE, _lib.KERNEL_SPLIT, _lib.KERNEL_PAIR, _lib.KERNEL_AUTO][it % 4]
+        staging = int(rng.choice([1 << 16, 1 << 18, 1 << 20, 1 << 24]))
+        with Context(kernel=kern, staging_bytes=staging) as c:
+            got = c.sha512_buffers(bufs)
+        bad = [i for i in range(n) if got[i] != want[i]]
+        assert not bad, (it, kern, staging, [(i, lens[i]) for i in bad[:5]])

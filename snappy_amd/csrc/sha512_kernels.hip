@@ -63,7 +63,8 @@ __device__ __forceinline__ void store_digest_be(uint8_t* out, const uint64_t H[8
 // ---------------------------------------------------------------------------
 // WIDE kernel: one lane per stream, 64 streams per wave, one wave per
 // workgroup.  The efficient form when there are enough streams to fill the
-// chip (>= ~130k lanes): every VALU instruction advances 64 streams.
+// chip: every VALU instruction advances 64 streams; saturates the VALUs at
+// ~1.05 TB/s from 65 536 streams on (profiles/r01_regime_sweep.txt).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void sha512_wide_kernel(const Job* __restrict__ jobs, uint32_t njobs,
                                                          uint64_t* __restrict__ state,

@@ -188,7 +188,7 @@ int snaphash_fill_synthetic_device(snaphash_ctx *ctx, void *d_base, const uint64
 
 /* ---- diagnostics ------------------------------------------------------------ */
 const char *snaphash_strerror(int code);
-const char *snaphash_last_error(const snaphash_ctx *ctx);
+const char *snaphash_last_error(const snaphash_ctx *ctx); /* ctx == NULL: why the last snaphash_init on this thread failed */
 void snaphash_get_stats(const snaphash_ctx *ctx, snaphash_stats *out);
 
 #ifdef __cplusplus

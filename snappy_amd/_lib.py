@@ -62,6 +62,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise OSError("%s not found: build it with `make -C snappy_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64, and a second runtime
+    # loaded before it ends up without a device ("no ROCm-capable device is detected").  In the
+    # Python mirror torch is always around (device memory, streams, torch.distributed), so load
+    # it first and let libsnaphash.so bind to the runtime that is already in the process.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, u64p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)
     L.snaphash_init.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
@@ -116,7 +124,7 @@ class Context:
         h = ctypes.c_void_p()
         rc = lib().snaphash_init(ctypes.byref(cfg), ctypes.byref(h))
         if rc:
-            raise SnaphashError(rc, "snaphash_init (is an MI355X/gfx950 visible?)")
+            raise SnaphashError(rc, "snaphash_init: " + lib().snaphash_last_error(None).decode(errors="replace"))
         self._h = h
 
     def close(self):

@@ -423,20 +423,31 @@ extern "C" {
 
 int snaphash_abi_version(void) { return SNAPHASH_ABI_VERSION; }
 
+static thread_local std::string g_init_error; // why the last snaphash_init on this thread failed
+
+static int init_fail(int code, const std::string& what, hipError_t e = hipSuccess)
+{
+    g_init_error = what + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string());
+    return code;
+}
+
 int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
 {
     if (!out) return SNAPHASH_EINVAL;
     *out = nullptr;
+    g_init_error.clear();
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SNAPHASH_EDEVICE;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return init_fail(SNAPHASH_EDEVICE, "hipGetDeviceCount found no device", e);
     int dev = -1;
     if (cfg && cfg->struct_size >= sizeof(snaphash_config)) dev = cfg->device;
-    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return SNAPHASH_EDEVICE;
-    if (dev >= ndev) return SNAPHASH_EINVAL;
+    if (dev < 0 && (e = hipGetDevice(&dev)) != hipSuccess) return init_fail(SNAPHASH_EDEVICE, "hipGetDevice", e);
+    if (dev >= ndev) return init_fail(SNAPHASH_EINVAL, "device ordinal out of range");
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SNAPHASH_EDEVICE;
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SNAPHASH_EDEVICE; // the code object is gfx950-only
-    if (hipSetDevice(dev) != hipSuccess) return SNAPHASH_EDEVICE;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return init_fail(SNAPHASH_EDEVICE, "hipGetDeviceProperties", e);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) // the code object is gfx950-only
+        return init_fail(SNAPHASH_EDEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    if ((e = hipSetDevice(dev)) != hipSuccess) return init_fail(SNAPHASH_EDEVICE, "hipSetDevice", e);
     snaphash_ctx* c = new (std::nothrow) snaphash_ctx();
     if (!c) return SNAPHASH_ENOMEM;
     c->device = dev;
@@ -447,7 +458,10 @@ int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
     }
     if (c->staging < (1u << 16)) c->staging = 1u << 16;
     if (!c->stream) {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SNAPHASH_EDEVICE; }
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+            delete c;
+            return init_fail(SNAPHASH_EDEVICE, "hipStreamCreateWithFlags", e);
+        }
         c->own_stream = true;
     }
     *out = c;
@@ -805,7 +819,7 @@ const char* snaphash_strerror(int code)
     }
 }
 
-const char* snaphash_last_error(const snaphash_ctx* c) { return c ? c->last_error.c_str() : ""; }
+const char* snaphash_last_error(const snaphash_ctx* c) { return c ? c->last_error.c_str() : g_init_error.c_str(); }
 
 void snaphash_get_stats(const snaphash_ctx* c, snaphash_stats* out)
 {

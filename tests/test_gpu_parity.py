@@ -348,3 +348,55 @@ def test_randomized_ragged_batches_all_kernels(built_lib):
             got = c.sha512_buffers(bufs)
         bad = [i for i in range(n) if got[i] != want[i]]
         assert not bad, (it, kern, staging, [(i, lens[i]) for i in bad[:5]])
+
+
+def test_config_c3_full_size_properties(built_lib, oracle):
+    """BASELINE config 3 at full size: 100 x 1 GiB streams (100 GiB resident in HBM), one launch,
+    8 388 609 blocks per stream.  The oracle cannot hash 100 GiB in seconds: two whole files are
+    checked bit-exact against it, all digests must be pairwise distinct, and a second pass over a
+    permuted stream order must reproduce the vector (order independence)."""
+    torch = _torch()
+    from snappy_amd import Context, synthetic
+    free, _ = torch.cuda.mem_get_info()
+    if free < (104 << 30):
+        pytest.skip("needs 104 GiB of free HBM")
+    lens = synthetic.config_sizes("C3")
+    off, total = synthetic.pack_offsets(lens)
+    idx = np.arange(len(lens), dtype=np.uint64)
+    with Context() as c:
+        dev = torch.empty(total, dtype=torch.uint8, device="cuda")
+        c.fill_synthetic_device(dev.data_ptr(), off, lens, idx)
+        out = torch.zeros((len(lens), 64), dtype=torch.uint8, device="cuda")
+        c.sha512_device(dev.data_ptr(), off, lens, out.data_ptr())
+        c.sync()
+        st = c.stats()
+        got = out.cpu().numpy()
+        perm = np.random.default_rng(4).permutation(len(lens))
+        out2 = torch.zeros_like(out)
+        c.sha512_device(dev.data_ptr(), off[perm].copy(), lens[perm].copy(), out2.data_ptr())
+        c.sync()
+        got2 = out2.cpu().numpy()
+        del dev
+    assert st["blocks"] == 100 * 8388609 and st["bytes_hashed"] == 100 << 30
+    assert (got2 == got[perm]).all()
+    assert len({r.tobytes() for r in got}) == 100
+    for i in (0, 99):
+        assert got[i].tobytes() == oracle.sha512(oracle.fill_synthetic(1 << 30, i).tobytes()), i
+
+
+def test_one_hip_runtime_whichever_is_used_first():
+    """A process that touches libsnaphash.so BEFORE torch.cuda must still see the GPU from both:
+    the binding loads torch's bundled HIP runtime first so that only one runtime owns the device."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from snappy_amd import Context\n"
+            "c = Context(); d = c.sha512_buffers([b'x'])[0].hex()\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "t = torch.zeros(4, device='cuda') + 1\n"
+            "assert float(t.sum()) == 4.0 and d.startswith('a4abd4448c49562d')\n"
+            "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]

@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C5"])
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "split", "pair"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg (0 = skip)")
@@ -196,11 +196,11 @@ def main():
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: %d tree(s) of %d files (%d x %d B + archive stand-in), HBM-resident, "
+            "config": {"workload": "%s: %d tree(s) of %d files (first of %d sized %d B; C1/C2 include a 1-file archive stand-in), HBM-resident, "
                                    "LPT-sharded over %d GPU(s)%s" % (
                                        args.workload, ntrees, len(tree), len(tree) - 1, int(tree[0]), world,
                                        ", RCCL all-gather of the digest vector" if world > 1 else ""),
-                       "files": int(len(sizes)), "bytes": total_bytes, "kernel": kname,
+                       "files": int(len(sizes)), "bytes": total_bytes, "kernel": kname, "launches_per_step": int(st["launches"]),
                        "sha512_blocks_per_step": int(st["blocks"]) * 1 if world == 1 else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,

@@ -165,6 +165,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- N > 1 only: the literal BASELINE config 4 (ONE tree sharded over the ranks), reported
+    # beside the headline so that both readings of "scaling" are on record -------------------
+    strong_leg = None
+    if (world > 1 or force_dist) and args.scaling == "weak":
+        plan_s = ShardPlan(tree, world)
+        mine_s = plan_s.members(rank)
+        lens_s = np.ascontiguousarray(tree[mine_s])
+        off_s, total_s = synthetic.pack_offsets(lens_s)
+        data_s = torch.empty(max(total_s, 16), dtype=torch.uint8, device="cuda")
+        ctx.fill_synthetic_device(data_s.data_ptr(), off_s, lens_s, np.ascontiguousarray(mine_s.astype(np.uint64)))
+        local_s = torch.zeros((plan_s.kmax, 64), dtype=torch.uint8, device="cuda")
+
+        def step_s():
+            ctx.sha512_device(data_s.data_ptr(), off_s, lens_s, local_s.data_ptr())
+            out = gather_digests(local_s, plan_s, force_collective=force_dist)
+            ctx.sync()
+            return out
+        for _ in range(2):
+            step_s()
+        fence()
+        ts = time.perf_counter()
+        nrep = max(3, min(10, args.steps))
+        for _ in range(nrep):
+            step_s()
+        fence()
+        el = time.perf_counter() - ts
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        strong_leg = {"workload": "ONE %s tree (%d files) LPT-sharded over %d GPU(s) + RCCL digest all-gather" %
+                                  (args.workload, len(tree), world),
+                      "value": round(float(tree.sum()) / 2**30 / (el / nrep), 3), "unit": "GiB/s",
+                      "ms_per_step": round(el / nrep * 1e3, 4), "steps": nrep,
+                      "note": "stream-count-bound: %d streams per GPU advance no faster than %d on one GPU "
+                              "(DESIGN.md sec. 5)" % (len(mine_s), len(tree))}
+        del data_s
+
     # ---- parity spot check, outside the timed region ---------------------------------
     digests = full.cpu().numpy()
     parity = None
@@ -209,6 +247,8 @@ def main():
                                  "and stream-count bound, not HBM bound (DESIGN.md)"},
             "parity": parity,
         }
+        if strong_leg is not None:
+            line["strong_scaling_leg"] = strong_leg
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(tree, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -37,6 +37,13 @@ try:
             st = c.stats()
             print("GPU writeHashes pass %d: %.3f s = %.2f GiB/s (kernel %.1f ms, h2d %.1f ms, %d launches)" %
                   (rep, dt, (n + 1) * size / 2**30 / dt, st["kernel_ms"], st["h2d_ms"], st["launches"]), flush=True)
+        for rep in range(2):  # the inverse pass (install-time Verify, row f1) over the same tree
+            t0 = time.perf_counter()
+            res = c.verify(build, y_gpu, tar)
+            dt = time.perf_counter() - t0
+            print("GPU Verify pass %d: %.3f s = %.2f GiB/s -> %s" % (rep, dt, (n + 1) * size / 2**30 / dt,
+                                                                     "match" if res is None else res), flush=True)
+            assert res is None
     t0 = time.perf_counter()
     y_cpu = oracle.hashes_yaml(build, tar)
     dt = time.perf_counter() - t0

@@ -38,3 +38,18 @@ def test_segment_carry(core, oracle):
         for split in (128, 256, 1024):
             if split < n:
                 assert core(rnd[:n], split) == oracle.sha512(rnd[:n]), (n, split)
+
+
+def test_round_constants_from_first_principles():
+    """K512 / IV512 in sha512_core.h against cube/square roots of the primes (FIPS 180-4 sec. 4.2.3, 5.3.5)."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gen_sha512_constants import constants
+    K, IV = constants()
+    text = open(os.path.join(ROOT, "snappy_amd", "csrc", "sha512_core.h")).read()
+    body = text[text.index("#define SNAPHASH_K512_LIST"):text.index("static constexpr uint64_t K512")]
+    got = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ULL", body)]
+    assert got == K
+    iv = text[text.index("IV512[8] = {"):]
+    assert [int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ULL", iv[:iv.index("};")])] == IV

@@ -400,3 +400,20 @@ def test_one_hip_runtime_whichever_is_used_first():
             "print('ok')\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+def test_more_streams_than_a_batch_holds(built_lib):
+    """6 000 streams through a 1 MiB staging buffer: more active streams than the engine packs per
+    batch (4 096) and a 256-byte quota, so every stream is cut into many segments and the batch
+    composition changes as streams finish."""
+    import hashlib
+    from snappy_amd import Context
+    rng = np.random.default_rng(77)
+    blob = rng.integers(0, 256, size=1 << 20, dtype=np.uint8).tobytes()
+    lens = rng.integers(0, 3000, size=6000)
+    bufs = [blob[int(o):int(o) + int(l)] for o, l in zip(rng.integers(0, (1 << 20) - 3000, size=6000), lens)]
+    with Context(staging_bytes=1 << 20) as c:
+        got = c.sha512_buffers(bufs)
+        st = c.stats()
+    assert st["launches"] > 8 and st["streams"] == 6000
+    assert all(g == hashlib.sha512(b).digest() for g, b in zip(got, bufs))

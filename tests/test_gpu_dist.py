@@ -1,0 +1,68 @@
+"""The sharded pass end to end with real hashing: two ranks (processes) share the one GPU of the
+test box, each hashes its LPT shard of a Zipf-sized file list through the C ABI, the digest slabs
+are gathered (gloo here, because RCCL refuses two ranks on one device; bench.py uses RCCL with one
+GPU per rank) and every rank must hold the full digest vector in walk order, bit-exact."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, sizes, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from snappy_amd import Context, synthetic
+        from snappy_amd.sharded import ShardPlan, gather_digests
+        plan = ShardPlan(sizes, world)
+        mine = plan.members(rank)
+        lens = np.ascontiguousarray(sizes[mine])
+        off, total = synthetic.pack_offsets(lens)
+        with Context(device=0) as ctx:
+            data = torch.empty(max(total, 16), dtype=torch.uint8, device="cuda")
+            ctx.fill_synthetic_device(data.data_ptr(), off, lens, np.ascontiguousarray(mine.astype(np.uint64)))
+            slab = torch.zeros((plan.kmax, 64), dtype=torch.uint8, device="cuda")
+            ctx.sha512_device(data.data_ptr(), off, lens, slab.data_ptr())
+            ctx.sync()
+            full = gather_digests(slab.cpu(), plan)
+        q.put((rank, full.numpy().tobytes(), int(len(mine))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_shard_hash_gather(oracle):
+    import torch.multiprocessing as mp
+    from snappy_amd import synthetic
+    sizes = np.minimum(synthetic.zipf_sizes(3000), np.uint64(1 << 22))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=280) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = b"".join(oracle.sha512(oracle.fill_synthetic(int(n), i).tobytes()) for i, n in enumerate(sizes))
+    assert sum(r[2] for r in res) == len(sizes)
+    for rank, blob, _ in res:
+        assert blob == want, rank

@@ -165,11 +165,13 @@ int ensure_slots(snaphash_ctx* c)
 
 // Kernel choice.  PAIR/SPLIT need one workgroup (64 streams, 140 KB of LDS) per CU
 // resident at once and pay two block-times of pipeline fill, so they are for few,
-// long streams; beyond 256 CUs x 64 streams the lane-per-stream kernel fills the
-// SIMDs by itself.  A heavy-tailed batch (BASELINE config 5: Zipf sizes) is cut in
-// two: the long head goes to PAIR (per-stream latency decides the makespan), the
-// short tail to WIDE.
-constexpr size_t kSplitMaxStreams = 256 * 64;
+// long streams: PAIR holds ~568 GB/s from 16 384 streams on (one workgroup per CU,
+// further workgroups queue), WIDE delivers streams x 16 MB/s until it saturates the
+// VALUs at 65 536 streams -- the curves cross at ~34 800 streams
+// (profiles/r01_regime_sweep.txt).  A heavy-tailed batch (BASELINE config 5: Zipf
+// sizes) is cut in two: the long head goes to PAIR (per-stream latency decides the
+// makespan), the short tail to WIDE.
+constexpr size_t kSplitMaxStreams = 34816;
 constexpr uint64_t kSplitMinBlocks = 32;
 
 uint64_t job_blocks(const Job& j) { return (j.nbytes >> 7) + 1; }

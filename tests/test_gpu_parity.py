@@ -223,12 +223,12 @@ def test_config_c2_full_size_properties(ctx, oracle):
 
 
 def test_config_c5_zipf_scaled_vs_oracle(built_lib, oracle):
-    """BASELINE config 5 (Zipf-mixed sizes) scaled to 20 000 files / ~2.7 GiB: every digest
+    """BASELINE config 5 (Zipf-mixed sizes) scaled to 50 000 files / ~2.9 GiB: every digest
     bit-exact against the oracle; with AUTO the batch is cut into a long head (PAIR kernel)
     and a short tail (WIDE kernel)."""
     torch = _torch()
     from snappy_amd import Context, synthetic
-    lens = np.minimum(synthetic.zipf_sizes(20000), np.uint64(1 << 25))  # cap the head at 32 MiB: keeps the run in seconds
+    lens = np.minimum(synthetic.zipf_sizes(50000), np.uint64(1 << 25))  # cap the head at 32 MiB: keeps the run in seconds
     off, total = synthetic.pack_offsets(lens)
     idx = np.arange(len(lens), dtype=np.uint64)
     with Context() as c:

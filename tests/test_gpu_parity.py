@@ -417,3 +417,19 @@ def test_more_streams_than_a_batch_holds(built_lib):
         st = c.stats()
     assert st["launches"] > 8 and st["streams"] == 6000
     assert all(g == hashlib.sha512(b).digest() for g, b in zip(got, bufs))
+
+
+def test_cli_hash_matches_coreutils_sha512sum(built_lib, tmp_path):
+    """A third independent implementation: `snaphash hash FILE...` prints what coreutils' sha512sum prints."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    from snappy_amd import synthetic
+    if not shutil.which("sha512sum"):
+        pytest.skip("coreutils sha512sum not installed")
+    build, tar = trees.make_synthetic_tree(str(tmp_path), [0, 1, 127, 128, 129, 5000, 65536, 100001, 7])
+    files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(build) for f in fs) + [tar]
+    cli = os.path.join(ROOT, "snappy_amd", "bin", "snaphash")
+    ours = subprocess.run([cli, "hash"] + files, stdout=subprocess.PIPE, check=True, timeout=120).stdout
+    theirs = subprocess.run(["sha512sum"] + files, stdout=subprocess.PIPE, check=True, timeout=120).stdout
+    assert ours == theirs

@@ -95,6 +95,22 @@ DEFINE_KERNEL(k_dppmov, , DPPMOV_I, DPPMOV_D)
 #define DPPADD_D(n) "v_add_co_u32_dpp %0, vcc, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
 DEFINE_KERNEL(k_dppadd, , DPPADD_I, DPPADD_D)
 
+#define DPPADDM_I(n) "v_add_co_u32_dpp %" #n ", vcc, %17, %" #n " row_half_mirror row_mask:0xf bank_mask:0x5\nv_addc_co_u32_dpp %" #n ", vcc, %17, %" #n ", vcc row_half_mirror row_mask:0xf bank_mask:0x5\n"
+#define DPPADDM_D(n) "v_add_co_u32_dpp %0, vcc, %17, %0 row_half_mirror row_mask:0xf bank_mask:0x5\nv_addc_co_u32_dpp %0, vcc, %17, %0, vcc row_half_mirror row_mask:0xf bank_mask:0x5\n"
+DEFINE_KERNEL(k_dppadd_pair_masked, , DPPADDM_I, DPPADDM_D)
+
+#define DPPADDU_I(n) "v_add_co_u32_dpp %" #n ", vcc, %17, %" #n " row_half_mirror row_mask:0xf bank_mask:0xf\nv_addc_co_u32_dpp %" #n ", vcc, %17, %" #n ", vcc row_half_mirror row_mask:0xf bank_mask:0xf\n"
+#define DPPADDU_D(n) "v_add_co_u32_dpp %0, vcc, %17, %0 row_half_mirror row_mask:0xf bank_mask:0xf\nv_addc_co_u32_dpp %0, vcc, %17, %0, vcc row_half_mirror row_mask:0xf bank_mask:0xf\n"
+DEFINE_KERNEL(k_dppadd_pair_unmasked, , DPPADDU_I, DPPADDU_D)
+
+#define DPPXOR_I(n) "v_xor_b32_dpp %" #n ", %17, %" #n " quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n"
+#define DPPXOR_D(n) "v_xor_b32_dpp %0, %17, %0 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n"
+DEFINE_KERNEL(k_dppxor_masked, , DPPXOR_I, DPPXOR_D)
+
+#define SWAP32_I(n) "v_permlane32_swap_b32 %" #n ", %17\n"
+#define SWAP32_D(n) "v_permlane32_swap_b32 %0, %0\n"
+DEFINE_KERNEL(k_permlane32_swap, , SWAP32_I, SWAP32_D)
+
 #define HMIR_I(n) "v_mov_b32_dpp %" #n ", %17 row_half_mirror row_mask:0xf bank_mask:0xf\n"
 #define HMIR_D(n) "v_mov_b32_dpp %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
 DEFINE_KERNEL(k_dpp_half_mirror, , HMIR_I, HMIR_D)
@@ -185,6 +201,10 @@ int main()
         RUN(k_dppmov, 16);
         RUN(k_dppadd, 16);
         RUN(k_dpp_half_mirror, 16);
+        RUN(k_dppadd_pair_masked, 32);
+        RUN(k_dppadd_pair_unmasked, 32);
+        RUN(k_dppxor_masked, 16);
+        RUN(k_permlane32_swap, 16);
         RUN(k_cndmask, 16);
         RUN(k_valu_plus_salu, 32);
         run("k_lds_mix(1ds+4valu)", k_lds_mix<false>, 20, w, d_cycles, d_sink);

@@ -1,0 +1,82 @@
+// Test-only driver: snappy_amd/csrc/hostpass.cpp under AddressSanitizer + UBSan (CPU build; GPU
+// sanitizers are not available on the pool).  Walks a tree, emits and re-parses its YAML, then
+// feeds the parser -- which reads untrusted hashes.yaml from packages -- thousands of mutated
+// documents.  Exit code 0 = no sanitizer report and all invariants held.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../snappy_amd/csrc/hostpass.h"
+
+using namespace snaphash;
+
+static uint64_t rng_state = 0x9e3779b97f4a7c15ULL;
+static uint32_t rnd()
+{
+    rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+    return (uint32_t)(rng_state >> 32);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) return 2;
+    std::vector<Record> recs;
+    int en = 0;
+    if (walk_tree(argv[1], recs, &en) != SNAPHASH_OK) return 3;
+    std::vector<uint8_t> dig(64 * (recs.size() + 1), 0xab);
+    std::string y;
+    if (emit_yaml(recs, dig.data(), dig.data() + 64, y) != SNAPHASH_OK) return 4;
+    ParsedHashes ph;
+    if (parse_yaml(y.data(), y.size(), ph) != SNAPHASH_OK || ph.files.size() != recs.size()) return 5;
+    for (size_t i = 0; i < recs.size(); ++i)
+        if (ph.files[i].name != recs[i].name) return 6;
+
+    FILE* f = fopen(argv[2], "rb");
+    if (!f) return 7;
+    std::string golden;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) golden.append(buf, n);
+    fclose(f);
+    static const char* const frag[] = {"\n- name: ", "\n  mode: ", "'", "\"", "\\", "\\x", "\\u12", ": ", "files:", "[]", "{}",
+                                       "\n  xattr:\n    a: b", "\n  size: ", "-", "#", "\t", "\r\n", "archive-sha512: ", "  "};
+    int ok = 0, bad = 0;
+    for (int it = 0; it < 20000; ++it) {
+        std::string m = (it & 1) ? golden : y;
+        const int edits = 1 + rnd() % 4;
+        for (int e = 0; e < edits && !m.empty(); ++e) {
+            const size_t pos = rnd() % m.size();
+            switch (rnd() % 5) {
+            case 0: m[pos] = (char)(rnd() & 0xff); break;
+            case 1: m.erase(pos, 1 + rnd() % 8); break;
+            case 2: m.insert(pos, frag[rnd() % (sizeof frag / sizeof *frag)]); break;
+            case 3: m.resize(pos); break;
+            default: m.insert(pos, 1 + rnd() % 3, (char)(rnd() & 0xff)); break;
+            }
+        }
+        ParsedHashes p;
+        const int rc = parse_yaml(m.data(), m.size(), p);
+        if (rc == SNAPHASH_OK) {
+            ++ok;
+            for (const ParsedRecord& r : p.files) {
+                char ms[11];
+                if (!r.has_name || !r.has_mode || mode_string(r.st_mode, ms) != SNAPHASH_OK) return 8; // accepted => well-formed
+            }
+        } else if (rc == SNAPHASH_EPARSE) {
+            ++bad;
+        } else {
+            return 9;
+        }
+    }
+    uint32_t mode;
+    if (mode_parse("", &mode) == SNAPHASH_OK) return 10;
+    std::vector<uint64_t> lens(1000);
+    std::vector<int32_t> shard(1000);
+    for (auto& l : lens) l = rnd() % (1u << 26);
+    if (lpt_assign(lens.data(), lens.size(), 8, shard.data()) != SNAPHASH_OK) return 11;
+    printf("asan driver ok: %zu records, %d mutated documents accepted, %d rejected\n", recs.size(), ok, bad);
+    return 0;
+}

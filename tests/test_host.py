@@ -201,3 +201,18 @@ def test_parse_yaml_reader_side(built_lib):
         with pytest.raises(SnaphashError) as e:
             _lib.parse_yaml(bad)
         assert e.value.code == _lib.EPARSE, bad
+
+
+def test_hostpass_under_asan_and_ubsan(tmp_path):
+    """hostpass.cpp (walk, emitter, parser of untrusted hashes.yaml, LPT) built with
+    -fsanitize=address,undefined and driven with 20 000 mutated documents."""
+    import subprocess
+    exe = str(tmp_path / "asan_hostpass")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-o", exe, os.path.join(ROOT, "tests", "asan_hostpass.cpp"),
+                           os.path.join(ROOT, "snappy_amd", "csrc", "hostpass.cpp")])
+    build, tar = trees.make_synthetic_tree(str(tmp_path / "t"), [5, 0, 300, 70000, 12, 1, 2, 3])
+    r = subprocess.run([exe, build, os.path.join(GOLDEN, "hashes_simple.yaml")], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr.decode()[-3000:])
+    assert b"asan driver ok" in r.stdout

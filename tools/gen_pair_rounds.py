@@ -60,6 +60,53 @@ def one_round(e, i, kw_prefetch, wait):
     kw = "KW%d" % (i & 3)
     if kw_prefetch is not None:
         e(("ds_read2_b64", "KW%d" % ((i + 2) & 3), "ADDR", kw_prefetch))
+    if ORDER.startswith("seed:"):
+        # experiment: a random topological order of the round's 19 non-DPP instructions (the four
+        # DPP adds stay last, in order); dependencies are read off the operand names
+        import random
+        body = [("alignbit", "Tl", x[0] + "h", x[0] + "l", "C1"), ("alignbit", "Th", x[0] + "l", x[0] + "h", "C1"),
+                ("alignbit", "Ul", x[0] + "h", x[0] + "l", "C2"), ("alignbit", "Uh", x[0] + "l", x[0] + "h", "C2"),
+                ("xor", "Tl", "Tl", "Ul"), ("xor", "Th", "Th", "Uh"), ("xor", "Tl", "Tl", x[0] + "l"),
+                ("xor", "Th", "Th", x[0] + "h"), ("alignbit", "Sl", "Th", "Tl", "C3"), ("alignbit", "Sh", "Tl", "Th", "C3"),
+                ("and", "Ml", x[2] + "l", "MB"), ("and", "Mh", x[2] + "h", "MB"), ("xor", "Ml", "Ml", x[0] + "l"),
+                ("xor", "Mh", "Mh", x[0] + "h"), ("bfi", "BFl", "Ml", x[1] + "l", x[2] + "l"),
+                ("bfi", "BFh", "Mh", x[1] + "h", x[2] + "h"), ("add64", "VV", "S", "BF"), ("add64", "TT", x[3], kw),
+                ("add64", "V2", "VV", "TT")]
+        def regs_of(t, write):
+            names = [t[1]] if write else list(t[2:])
+            out = set()
+            for nme in names:
+                out |= {nme + "l", nme + "h"} if t[0] == "add64" else {nme}
+            return out
+        rnd = random.Random(int(ORDER[5:]) * 1000 + (i & 3))
+        done, left = [], list(range(len(body)))
+        while left:
+            ready = []
+            for k in left:  # all earlier (program-order) instructions that conflict with k must be done
+                ok = True
+                for j in range(k):
+                    if j in left:
+                        wj, rj = regs_of(body[j], True), regs_of(body[j], False)
+                        wk, rk = regs_of(body[k], True), regs_of(body[k], False)
+                        if (wj & rk) or (wj & wk) or (rj & wk):
+                            ok = False
+                            break
+                if ok:
+                    ready.append(k)
+            k = rnd.choice(ready)
+            left.remove(k)
+            done.append(k)
+        for k in done:
+            if body[k][0] == "add64" and body[k][1] == "TT" and wait is not None:
+                e(("waitcnt", wait))
+            e(body[k])
+        if wait is not None and not any(body[k][1] == "TT" for k in done):
+            e(("waitcnt", wait))
+        e(("add_co_dpp", x[3] + "l", x[3] + "l", "V2l", A_BANKS))
+        e(("addc_co_dpp", x[3] + "h", x[3] + "h", "V2h", A_BANKS))
+        e(("add_co_dpp", x[3] + "l", "V2l", "VVl", B_BANKS))
+        e(("addc_co_dpp", x[3] + "h", "V2h", "VVh", B_BANKS))
+        return
     if ORDER == "interleave":
         e(("alignbit", "Tl", x[0] + "h", x[0] + "l", "C1"))
         e(("and", "Ml", x[2] + "l", "MB"))

@@ -168,10 +168,11 @@ int ensure_slots(snaphash_ctx* c)
 // long streams: PAIR holds ~568 GB/s from 16 384 streams on (one workgroup per CU,
 // further workgroups queue), WIDE delivers streams x 16 MB/s until it saturates the
 // VALUs at 65 536 streams -- the curves cross at ~34 800 streams
-// (profiles/r01_regime_sweep.txt).  A heavy-tailed batch (BASELINE config 5: Zipf
+// (profiles/r01_regime_sweep.txt); the cap is two full passes of 256 workgroups, because a
+// third, mostly empty pass would cost a whole stream-time more.  A heavy-tailed batch (BASELINE config 5: Zipf
 // sizes) is cut in two: the long head goes to PAIR (per-stream latency decides the
 // makespan), the short tail to WIDE.
-constexpr size_t kSplitMaxStreams = 34816;
+constexpr size_t kSplitMaxStreams = 32768;
 constexpr uint64_t kSplitMinBlocks = 32;
 
 uint64_t job_blocks(const Job& j) { return (j.nbytes >> 7) + 1; }

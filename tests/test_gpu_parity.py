@@ -14,6 +14,16 @@ import trees
 pytestmark = pytest.mark.gpu
 
 
+def _cli():
+    """snappy_amd/bin/snaphash, built on demand (make builds the library and the CLI together)."""
+    import subprocess
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "snappy_amd", "bin", "snaphash")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "snappy_amd", "csrc")])
+    return cli
+
+
 def _torch():
     import torch
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
@@ -266,8 +276,7 @@ def test_cli_tree_and_verify(built_lib, tmp_path):
     """snappy_amd/bin/snaphash (plain C over include/snaphash.h): the golden tree through the CLI."""
     import subprocess
     from conftest import ROOT
-    cli = os.path.join(ROOT, "snappy_amd", "bin", "snaphash")
-    assert os.path.exists(cli), "build with make -C snappy_amd/csrc"
+    cli = _cli()
     build, tar = trees.make_simple_tree(str(tmp_path))
     want = open(os.path.join(GOLDEN, "hashes_simple.yaml"), "rb").read()
     got = subprocess.run([cli, "tree", build, tar], stdout=subprocess.PIPE, check=True, timeout=120).stdout
@@ -429,7 +438,7 @@ def test_cli_hash_matches_coreutils_sha512sum(built_lib, tmp_path):
         pytest.skip("coreutils sha512sum not installed")
     build, tar = trees.make_synthetic_tree(str(tmp_path), [0, 1, 127, 128, 129, 5000, 65536, 100001, 7])
     files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(build) for f in fs) + [tar]
-    cli = os.path.join(ROOT, "snappy_amd", "bin", "snaphash")
+    cli = _cli()
     ours = subprocess.run([cli, "hash"] + files, stdout=subprocess.PIPE, check=True, timeout=120).stdout
     theirs = subprocess.run(["sha512sum"] + files, stdout=subprocess.PIPE, check=True, timeout=120).stdout
     assert ours == theirs

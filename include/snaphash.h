@@ -137,6 +137,28 @@ int snaphash_verify(snaphash_ctx *ctx, const char *inst_dir, const char *data_ta
 
 void snaphash_free(void *p);
 
+/* ---- neighbouring scan: helpers.FilesAreEqual / DirUpdated -------- */
+
+/* helpers.FilesAreEqual (helpers/cmp.go:31-60), batched: equal[i] = 1 iff a[i] and b[i] both
+ * open, have the same size and the same bytes; as upstream, any open/stat/read error makes the
+ * pair "not equal" (it is not an error of the call).  The bytes are compared on the GPU. */
+int snaphash_files_equal(snaphash_ctx *ctx, const char *const *a, const char *const *b, size_t n,
+                         uint8_t *equal);
+
+/* The same for byte ranges already resident in HBM: [d_a+off_a[i], +lens[i]) against
+ * [d_b+off_b[i], +lens[i]).  Offsets (host arrays) and bases 16-byte aligned; d_equal is device
+ * memory, n bytes.  Enqueues on the ctx stream; snaphash_sync waits.  HBM-bound: 2 bytes read
+ * per byte compared. */
+int snaphash_ranges_equal_device(snaphash_ctx *ctx, const void *d_a, const uint64_t *off_a,
+                                 const void *d_b, const uint64_t *off_b, const uint64_t *lens,
+                                 size_t n, void *d_equal);
+
+/* helpers.DirUpdated (helpers/cmp.go:88-114): the non-directory entries of dir_a (Glob order)
+ * that also exist in dir_b and differ from them, each with pfx prepended.  *names_out is a
+ * malloc'd sequence of *count NUL-terminated strings laid end to end (snaphash_free). */
+int snaphash_dir_updated(snaphash_ctx *ctx, const char *dir_a, const char *dir_b, const char *pfx,
+                         char **names_out, size_t *count);
+
 /* ---- host-side pieces of the pass (no device needed) ----------------------- */
 
 typedef struct snaphash_records snaphash_records;

@@ -45,6 +45,11 @@ def lib():
         L.oracle_write_hashes.restype = ctypes.c_int
         L.oracle_free.argtypes = [ctypes.c_void_p]
         L.oracle_free.restype = None
+        L.oracle_files_equal.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        L.oracle_files_equal.restype = ctypes.c_int
+        L.oracle_dir_updated.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p),
+                                         ctypes.POINTER(ctypes.c_size_t)]
+        L.oracle_dir_updated.restype = ctypes.c_int
         L.oracle_fill_synthetic.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.oracle_fill_synthetic.restype = None
         _lib = L
@@ -116,3 +121,21 @@ def fill_synthetic(length: int, file_index: int):
     if length:
         lib().oracle_fill_synthetic(a.ctypes.data, length, file_index)
     return a
+
+
+def files_equal(a: str, b: str) -> bool:
+    """helpers.FilesAreEqual (helpers/cmp.go:31-60)."""
+    return bool(lib().oracle_files_equal(os.fsencode(a), os.fsencode(b)))
+
+
+def dir_updated(dir_a: str, dir_b: str, pfx: str = ""):
+    """helpers.DirUpdated (helpers/cmp.go:88-114) -> set of names (the Go map's keys)."""
+    p, n = ctypes.c_void_p(), ctypes.c_size_t()
+    lib().oracle_dir_updated(os.fsencode(dir_a), os.fsencode(dir_b), pfx.encode(), ctypes.byref(p), ctypes.byref(n))
+    try:
+        text = ctypes.string_at(p.value).decode()
+    finally:
+        lib().oracle_free(p)
+    out = set(text.splitlines())
+    assert len(out) == n.value
+    return out

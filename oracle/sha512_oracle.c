@@ -13,6 +13,9 @@
  *                                files get size+sha512, yaml.Marshal
  *   snappy/hashes.go:33-57       yamlFileMode.MarshalYAML ("frw-r--r--")
  *   snappy/hashes.go:93-110      fileHash / hashesYaml field order
+ *   helpers/cmp.go:28-114        FilesAreEqual / streamsEqual (16 KiB ReadAtLeast
+ *                                loop) / DirUpdated -- SURVEY row f4, pinned by the
+ *                                cases of helpers/cmp_test.go:30-140
  *
  * The arithmetic itself lives outside /root/reference: Go's standard library
  * crypto/sha512 (Go version unpinned, debian/control:11 says golang-go).  Its
@@ -361,4 +364,83 @@ void oracle_fill_synthetic(uint8_t *dst, uint64_t len, uint64_t file_index)
         z ^= z >> 31;
         for (int b = 0; b < 8 && i < len; b++, i++) dst[i] = (uint8_t)(z >> (8 * b));
     }
+}
+
+/* ---- helpers.FilesAreEqual / streamsEqual / DirUpdated (helpers/cmp.go:28-114), row f4 ------ */
+
+/* io.ReadAtLeast(f, buf, bufsz): fills buf unless EOF intervenes; returns bytes read, *eof says
+ * whether the stream ended (0 bytes: io.EOF; fewer than bufsz: io.ErrUnexpectedEOF), *err a read error. */
+static size_t read_at_least(int fd, uint8_t *buf, size_t want, int *eof, int *err)
+{
+    size_t got = 0;
+    *eof = 0; *err = 0;
+    while (got < want) {
+        ssize_t r = read(fd, buf + got, want - got);
+        if (r < 0) { if (errno == EINTR) continue; *err = 1; break; }
+        if (r == 0) { *eof = 1; break; }
+        got += (size_t)r;
+    }
+    return got;
+}
+
+int oracle_files_equal(const char *a, const char *b) /* cmp.go:31-60 */
+{
+    enum { BUFSZ = 16 * 1024 }; /* cmp.go:27 */
+    int fa = open(a, O_RDONLY);
+    if (fa < 0) return 0;
+    int fb = open(b, O_RDONLY);
+    if (fb < 0) { close(fa); return 0; }
+    struct stat sa, sb;
+    int eq = 0;
+    if (fstat(fa, &sa) == 0 && fstat(fb, &sb) == 0 && sa.st_size == sb.st_size) {
+        static __thread uint8_t bufa[BUFSZ], bufb[BUFSZ];
+        for (;;) { /* streamsEqual, cmp.go:62-86 */
+            int eofa, eofb, erra, errb;
+            size_t ra = read_at_least(fa, bufa, BUFSZ, &eofa, &erra);
+            size_t rb = read_at_least(fb, bufb, BUFSZ, &eofb, &errb);
+            if (erra || errb) { eq = 0; break; }
+            if (eofa && ra == 0 && eofb && rb == 0) { eq = 1; break; }     /* both io.EOF */
+            if ((eofa || eofb) && !(eofa && eofb && ra && rb)) { eq = 0; break; } /* only "both ErrUnexpectedEOF" may still be equal */
+            if (ra != rb || memcmp(bufa, bufb, ra) != 0) { eq = 0; break; }
+        }
+    }
+    close(fa); close(fb);
+    return eq;
+}
+
+/* DirUpdated: names (pfx prepended) one per line into *out (oracle_free). cmp.go:88-114 */
+int oracle_dir_updated(const char *dir_a, const char *dir_b, const char *pfx, char **out, size_t *count)
+{
+    sbuf s = {0, 0, 0};
+    size_t k = 0;
+    char **names = 0; size_t n = 0, cap = 0;
+    DIR *d = opendir(dir_a);
+    if (d) {
+        struct dirent *de;
+        while ((de = readdir(d))) {
+            if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
+            if (n == cap) { cap = cap ? cap * 2 : 64; names = realloc(names, cap * sizeof *names); }
+            names[n++] = strdup(de->d_name);
+        }
+        closedir(d);
+    }
+    qsort(names, n, sizeof *names, cmp_names); /* filepath.Glob sorts */
+    for (size_t i = 0; i < n; i++) {
+        size_t la = strlen(dir_a) + strlen(names[i]) + 2, lb = strlen(dir_b) + strlen(names[i]) + 2;
+        char *fa = malloc(la), *fb = malloc(lb);
+        snprintf(fa, la, "%s/%s", dir_a, names[i]);
+        snprintf(fb, lb, "%s/%s", dir_b, names[i]);
+        struct stat st;
+        int isdir = (stat(fa, &st) == 0 && S_ISDIR(st.st_mode)); /* IsDirectory (helpers.go:227) */
+        if (!isdir && stat(fb, &st) == 0 /* FileExists */ && !oracle_files_equal(fa, fb)) {
+            sb_puts(&s, pfx ? pfx : ""); sb_puts(&s, names[i]); sb_puts(&s, "\n");
+            k++;
+        }
+        free(fa); free(fb); free(names[i]);
+    }
+    free(names);
+    if (!s.p) sb_puts(&s, "");
+    *out = s.p;
+    *count = k;
+    return 0;
 }

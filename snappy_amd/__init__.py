@@ -11,8 +11,8 @@ computes a digest on the CPU.
 """
 from . import _lib
 from ._lib import Context, SnaphashError
-from .helpers import Sha512sum, Sha512sumBatch
+from .helpers import Sha512sum, Sha512sumBatch, FilesAreEqual, DirUpdated
 from .hashes import writeHashes, getHashes, Verify, yamlFileMode
 
-__all__ = ["Context", "SnaphashError", "Sha512sum", "Sha512sumBatch", "writeHashes", "getHashes", "Verify",
+__all__ = ["Context", "SnaphashError", "Sha512sum", "Sha512sumBatch", "FilesAreEqual", "DirUpdated", "writeHashes", "getHashes", "Verify",
            "yamlFileMode", "_lib"]

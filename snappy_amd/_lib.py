@@ -20,6 +20,7 @@ EXPORTS = [
     "snaphash_init", "snaphash_destroy", "snaphash_abi_version",
     "snaphash_sha512_files", "snaphash_sha512_buffers", "snaphash_sha512_device", "snaphash_sync",
     "snaphash_tree", "snaphash_write_hashes", "snaphash_verify", "snaphash_free",
+    "snaphash_files_equal", "snaphash_ranges_equal_device", "snaphash_dir_updated",
     "snaphash_walk", "snaphash_records_count", "snaphash_records_get", "snaphash_records_free",
     "snaphash_emit_yaml", "snaphash_parse_yaml", "snaphash_records_sha512_hex", "snaphash_mode_string", "snaphash_mode_parse", "snaphash_lpt_assign",
     "snaphash_fill_synthetic_device", "snaphash_strerror", "snaphash_last_error", "snaphash_get_stats",
@@ -83,6 +84,10 @@ def lib():
     L.snaphash_tree.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.snaphash_write_hashes.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
     L.snaphash_verify.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, sz, ctypes.POINTER(Mismatch)]
+    L.snaphash_files_equal.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), sz, vp]
+    L.snaphash_ranges_equal_device.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp]
+    L.snaphash_dir_updated.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp),
+                                       ctypes.POINTER(sz)]
     L.snaphash_free.argtypes = [vp]
     L.snaphash_free.restype = None
     L.snaphash_walk.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
@@ -204,6 +209,35 @@ class Context:
             return (m.kind, m.name.decode(errors="replace"))
         self._check(rc)
         return None
+
+    # ---- neighbouring scan: helpers.FilesAreEqual / DirUpdated ------------------------------
+    def files_equal(self, pairs):
+        """[(a, b)] -> [bool]; like helpers.FilesAreEqual any open/stat/read error means False."""
+        n = len(pairs)
+        a = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(p[0]) for p in pairs])
+        b = (ctypes.c_char_p * max(n, 1))(*[os.fsencode(p[1]) for p in pairs])
+        out = ctypes.create_string_buffer(max(n, 1))
+        self._check(lib().snaphash_files_equal(self._h, a, b, n, out))
+        return [bool(x) for x in out.raw[:n]]
+
+    def ranges_equal_device(self, d_a, off_a, d_b, off_b, lens, d_equal):
+        self._check(lib().snaphash_ranges_equal_device(self._h, d_a, off_a.ctypes.data, d_b, off_b.ctypes.data,
+                                                       lens.ctypes.data, len(lens), d_equal))
+
+    def dir_updated(self, dir_a, dir_b, pfx=""):
+        """helpers.DirUpdated -> {name: True} like the Go map."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(lib().snaphash_dir_updated(self._h, os.fsencode(dir_a), os.fsencode(dir_b), pfx.encode(),
+                                               ctypes.byref(p), ctypes.byref(n)))
+        try:
+            names, addr = {}, p.value
+            for _ in range(n.value):
+                s_ = ctypes.string_at(addr)
+                names[s_.decode(errors="surrogateescape")] = True
+                addr += len(s_) + 1
+            return names
+        finally:
+            lib().snaphash_free(p)
 
     def stats(self):
         s = Stats()

@@ -23,6 +23,18 @@ static_assert(sizeof(Job) == 32, "Job is 32 bytes");
 hipError_t launch_wide(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
 hipError_t launch_pair(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
 hipError_t launch_split(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
+// Byte-range comparison (helpers.FilesAreEqual, reference helpers/cmp.go:31-86, batched): one
+// chunk = up to kCmpChunk bytes of one pair; equal[pair] is cleared when any chunk differs.
+constexpr uint32_t kCmpChunk = 256u << 10;
+struct CmpChunk {
+    uint64_t a;      // device address of the chunk on the A side (16-byte aligned)
+    uint64_t b;      // ... on the B side
+    uint32_t nbytes; // <= kCmpChunk
+    uint32_t pair;   // row of equal[]
+};
+static_assert(sizeof(CmpChunk) == 24, "CmpChunk is 24 bytes");
+hipError_t launch_compare(const CmpChunk* d_chunks, uint32_t nchunks, uint8_t* d_equal, hipStream_t s);
+
 hipError_t launch_fill_synthetic(uint8_t* d_base, const uint64_t* d_offsets, const uint64_t* d_lens,
                                  const uint64_t* d_findex, uint32_t nfiles, uint64_t max_len, hipStream_t s);
 

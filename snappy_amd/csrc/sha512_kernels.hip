@@ -462,7 +462,62 @@ __global__ __launch_bounds__(256) void fill_synthetic_kernel(uint8_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// Range comparison kernel (helpers.FilesAreEqual / streamsEqual, reference
+// helpers/cmp.go:31-86): pure streaming, 2 bytes read per byte compared, HBM-bound.
+// One 256-thread workgroup per chunk; every lane XORs 16-byte pieces of both sides
+// (coalesced dwordx4, 4 pieces in flight per lane per side), bytes past the end of
+// the range are masked out of the last piece, and a differing chunk clears its
+// pair's flag (all writers store 0: no ordering needed).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ranges_equal_kernel(const CmpChunk* __restrict__ chunks, uint32_t nchunks,
+                                                           uint8_t* __restrict__ equal)
+{
+    const uint32_t ci = blockIdx.x;
+    if (ci >= nchunks) return;
+    const CmpChunk ch = chunks[ci];
+    const uint8_t* pa = reinterpret_cast<const uint8_t*>(ch.a);
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(ch.b);
+    const uint32_t npieces = (ch.nbytes + 15u) >> 4;
+    const uint32_t nwhole = ch.nbytes >> 4; // pieces that lie entirely inside the range
+    uint32_t diff = 0;
+    uint32_t p = threadIdx.x;
+    for (; p + 768u < nwhole; p += 1024u) { // 4 independent whole pieces per lane per trip
+        uint4 xa[4], xb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xa[k] = load_u4(pa + (uint64_t)(p + 256u * k) * 16u);
+            xb[k] = load_u4(pb + (uint64_t)(p + 256u * k) * 16u);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            diff |= (xa[k].x ^ xb[k].x) | (xa[k].y ^ xb[k].y) | (xa[k].z ^ xb[k].z) | (xa[k].w ^ xb[k].w);
+    }
+    for (; p < npieces; p += 256u) {
+        const uint4 xa = load_u4(pa + (uint64_t)p * 16u), xb = load_u4(pb + (uint64_t)p * 16u);
+        uint32_t d[4] = {xa.x ^ xb.x, xa.y ^ xb.y, xa.z ^ xb.z, xa.w ^ xb.w};
+        if (p == npieces - 1u && (ch.nbytes & 15u)) { // keep only the bytes that belong to the range
+            const uint32_t valid = ch.nbytes & 15u;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int nv = (int)valid - 4 * w; // valid bytes in dword w
+                if (nv <= 0) d[w] = 0;
+                else if (nv < 4) d[w] &= (1u << (8 * nv)) - 1u;
+            }
+        }
+        diff |= d[0] | d[1] | d[2] | d[3];
+    }
+    if (__any(diff != 0) && (threadIdx.x & 63u) == 0) equal[ch.pair] = 0;
+}
+
 } // namespace
+
+hipError_t launch_compare(const CmpChunk* d_chunks, uint32_t nchunks, uint8_t* d_equal, hipStream_t s)
+{
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(ranges_equal_kernel, dim3(nchunks), dim3(256), 0, s, d_chunks, nchunks, d_equal);
+    return hipGetLastError();
+}
 
 hipError_t launch_wide(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s)
 {

@@ -8,6 +8,7 @@
 //   snappy/build.go:216-270     writeHashes: archive digest first, then the walk;
 //                               the first error aborts, nothing is written
 // Hashing happens on the GPU only; there is no host fallback in this file.
+#include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
@@ -72,6 +73,12 @@ struct snaphash_ctx {
     size_t state_cap = 0; // streams
     uint8_t* d_digests = nullptr;
     size_t digests_cap = 0; // streams
+
+    CmpChunk* h_chunks = nullptr; // pinned (range comparison)
+    CmpChunk* d_chunks = nullptr;
+    size_t chunks_cap = 0;
+    uint8_t* d_equal = nullptr;
+    size_t equal_cap = 0;
 
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
@@ -485,6 +492,9 @@ void snaphash_destroy(snaphash_ctx* c)
         if (s.copied) (void)hipEventDestroy(s.copied);
     }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->h_chunks) (void)hipHostFree(c->h_chunks);
+    if (c->d_chunks) (void)hipFree(c->d_chunks);
+    if (c->d_equal) (void)hipFree(c->d_equal);
     if (c->h_jobs) (void)hipHostFree(c->h_jobs);
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -704,6 +714,240 @@ int snaphash_verify(snaphash_ctx* c, const char* inst_dir, const char* data_tar,
 }
 
 void snaphash_free(void* p) { free(p); }
+
+// ---- helpers.FilesAreEqual / DirUpdated (row f4) ----------------------------------------------
+
+namespace {
+
+int ensure_chunks(snaphash_ctx* c, size_t n)
+{
+    if (n <= c->chunks_cap) return SNAPHASH_OK;
+    const size_t want = std::max<size_t>(n, 4096);
+    if (c->h_chunks) (void)hipHostFree(c->h_chunks);
+    if (c->d_chunks) (void)hipFree(c->d_chunks);
+    c->h_chunks = nullptr; c->d_chunks = nullptr; c->chunks_cap = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_chunks, want * sizeof(CmpChunk), hipHostMallocDefault));
+    HIP_TRY(c, hipMalloc((void**)&c->d_chunks, want * sizeof(CmpChunk)));
+    c->chunks_cap = want;
+    return SNAPHASH_OK;
+}
+
+// Ranges (device addresses) -> chunk table -> kernel.  d_equal must hold one byte per pair.
+int launch_compare_ranges(snaphash_ctx* c, const std::vector<uint64_t>& a, const std::vector<uint64_t>& b,
+                          const std::vector<uint64_t>& lens, uint8_t* d_equal)
+{
+    const size_t n = lens.size();
+    size_t nchunks = 0;
+    for (size_t i = 0; i < n; ++i) nchunks += (size_t)((lens[i] + kCmpChunk - 1) / kCmpChunk);
+    if (nchunks > 0xffffffffull) return fail(c, SNAPHASH_EINVAL, "too many comparison chunks");
+    int rc = ensure_chunks(c, nchunks);
+    if (rc) return rc;
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i)
+        for (uint64_t off = 0; off < lens[i]; off += kCmpChunk) {
+            CmpChunk& ch = c->h_chunks[k++];
+            ch.a = a[i] + off;
+            ch.b = b[i] + off;
+            ch.nbytes = (uint32_t)std::min<uint64_t>(kCmpChunk, lens[i] - off);
+            ch.pair = (uint32_t)i;
+        }
+    HIP_TRY(c, hipMemsetAsync(d_equal, 1, n, c->stream)); // equal until a chunk says otherwise
+    HIP_TRY(c, hipMemcpyAsync(c->d_chunks, c->h_chunks, nchunks * sizeof(CmpChunk), hipMemcpyHostToDevice, c->stream));
+    EventPair* ev = next_events(c, 0);
+    if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
+    HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+    hipError_t e = launch_compare(c->d_chunks, (uint32_t)nchunks, d_equal, c->stream);
+    if (e != hipSuccess) return fail(c, SNAPHASH_EDEVICE, std::string("compare launch: ") + hipGetErrorString(e));
+    HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+    c->stats.launches++;
+    c->pending = true;
+    return SNAPHASH_OK;
+}
+
+struct CmpPair { size_t idx; uint64_t len, done; bool failed; };
+
+// Reads [off, off+n) of path into dst; false on any error or short file (upstream: not equal).
+bool read_exact(const char* path, uint64_t off, uint64_t n, uint8_t* dst)
+{
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    uint64_t got = 0;
+    while (got < n) {
+        const ssize_t r = pread(fd, dst + got, n - got, (off_t)(off + got));
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) break;
+        got += (uint64_t)r;
+    }
+    close(fd);
+    return got == n;
+}
+
+int files_equal_impl(snaphash_ctx* c, const char* const* a, const char* const* b, size_t n, uint8_t* equal)
+{
+    std::vector<CmpPair> todo;
+    for (size_t i = 0; i < n; ++i) {
+        equal[i] = 0;
+        if (!a[i] || !b[i]) return fail(c, SNAPHASH_EINVAL, "NULL path");
+        struct stat sa, sb; // os.Open + Stat on both; any failure or a size difference: not equal (cmp.go:31-56)
+        if (stat(a[i], &sa) != 0 || stat(b[i], &sb) != 0) continue;
+        if (access(a[i], R_OK) != 0 || access(b[i], R_OK) != 0) continue;
+        if (sa.st_size != sb.st_size) continue;
+        if (S_ISDIR(sa.st_mode) || S_ISDIR(sb.st_mode)) continue; // a read of a directory fails: not equal
+        if (sa.st_size == 0) { equal[i] = 1; continue; }
+        todo.push_back(CmpPair{i, (uint64_t)sa.st_size, 0, false});
+        c->stats.bytes_hashed += (uint64_t)sa.st_size;
+    }
+    c->stats.streams = n;
+    if (todo.empty()) return SNAPHASH_OK;
+    int rc = ensure_slots(c);
+    if (rc) return rc;
+    for (const CmpPair& p : todo) equal[p.idx] = 1; // AND-ed down batch by batch
+    const uint64_t S = c->staging;
+    size_t first = 0;
+    while (first < todo.size()) {
+        // pack segments of consecutive pairs into the two staging buffers (A side: slot 0, B side: slot 1)
+        struct Seg { size_t t; uint64_t at, off, n; };
+        std::vector<Seg> segs;
+        uint64_t used = 0;
+        size_t t = first;
+        while (t < todo.size()) {
+            const uint64_t at = (used + kAlign - 1) & ~(uint64_t)(kAlign - 1);
+            if (at >= S) break;
+            const uint64_t take = std::min<uint64_t>(todo[t].len - todo[t].done, (S - at) & ~(uint64_t)15);
+            if (take == 0) break;
+            segs.push_back(Seg{t, at, todo[t].done, take});
+            used = at + take;
+            todo[t].done += take;
+            if (todo[t].done < todo[t].len) break; // buffer full mid-file: the rest goes in the next batch
+            ++t;
+        }
+        std::vector<uint8_t> ok(segs.size(), 1);
+        {
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= segs.size()) return;
+                    const Seg& g = segs[i];
+                    const CmpPair& p = todo[g.t];
+                    if (!read_exact(a[p.idx], g.off, g.n, c->slot[0].h_buf + g.at) ||
+                        !read_exact(b[p.idx], g.off, g.n, c->slot[1].h_buf + g.at))
+                        ok[i] = 0;
+                }
+            };
+            const unsigned T = (unsigned)std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
+                                                          std::max<size_t>(1, segs.size() / 2));
+            std::vector<std::thread> th;
+            for (unsigned k = 1; k < T; ++k) th.emplace_back(worker);
+            worker();
+            for (auto& x : th) x.join();
+        }
+        if (segs.size() > c->equal_cap) {
+            if (c->d_equal) (void)hipFree(c->d_equal);
+            c->d_equal = nullptr; c->equal_cap = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->d_equal, std::max<size_t>(segs.size(), 4096)));
+            c->equal_cap = std::max<size_t>(segs.size(), 4096);
+        }
+        EventPair* ev = next_events(c, 1);
+        if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
+        HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->slot[0].d_buf, c->slot[0].h_buf, used, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->slot[1].d_buf, c->slot[1].h_buf, used, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+        std::vector<uint64_t> va(segs.size()), vb(segs.size()), vl(segs.size());
+        for (size_t i = 0; i < segs.size(); ++i) {
+            va[i] = (uint64_t)(uintptr_t)(c->slot[0].d_buf + segs[i].at);
+            vb[i] = (uint64_t)(uintptr_t)(c->slot[1].d_buf + segs[i].at);
+            vl[i] = segs[i].n;
+        }
+        rc = launch_compare_ranges(c, va, vb, vl, c->d_equal);
+        if (rc) return rc;
+        std::vector<uint8_t> res(segs.size());
+        HIP_TRY(c, hipMemcpyAsync(res.data(), c->d_equal, segs.size(), hipMemcpyDeviceToHost, c->stream));
+        rc = sync_ctx(c);
+        if (rc) return rc;
+        for (size_t i = 0; i < segs.size(); ++i)
+            if (!ok[i] || !res[i]) equal[todo[segs[i].t].idx] = 0;
+        first = (t < todo.size() && todo[t].done < todo[t].len) ? t : t; // t is the first pair with bytes left
+        while (first < todo.size() && todo[first].done >= todo[first].len) ++first;
+    }
+    return SNAPHASH_OK;
+}
+
+} // namespace
+
+int snaphash_files_equal(snaphash_ctx* c, const char* const* a, const char* const* b, size_t n, uint8_t* equal)
+{
+    if (!c || (n && (!a || !b || !equal))) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = sync_ctx(c);
+    if (rc) return rc;
+    begin_call(c);
+    rc = files_equal_impl(c, a, b, n, equal);
+    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    return rc;
+}
+
+int snaphash_ranges_equal_device(snaphash_ctx* c, const void* d_a, const uint64_t* off_a, const void* d_b,
+                                 const uint64_t* off_b, const uint64_t* lens, size_t n, void* d_equal)
+{
+    if (!c || (n && (!d_a || !d_b || !off_a || !off_b || !lens || !d_equal))) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    if ((((uintptr_t)d_a) | ((uintptr_t)d_b)) & 15) return fail(c, SNAPHASH_EINVAL, "bases must be 16-byte aligned");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = sync_ctx(c);
+    if (rc) return rc;
+    begin_call(c);
+    if (n == 0) return SNAPHASH_OK;
+    std::vector<uint64_t> va(n), vb(n), vl(n);
+    for (size_t i = 0; i < n; ++i) {
+        if ((off_a[i] | off_b[i]) & 15) return fail(c, SNAPHASH_EINVAL, "offsets must be 16-byte aligned");
+        va[i] = (uint64_t)(uintptr_t)d_a + off_a[i];
+        vb[i] = (uint64_t)(uintptr_t)d_b + off_b[i];
+        vl[i] = lens[i];
+        c->stats.bytes_hashed += lens[i];
+    }
+    c->stats.streams = n;
+    return launch_compare_ranges(c, va, vb, vl, (uint8_t*)d_equal);
+}
+
+int snaphash_dir_updated(snaphash_ctx* c, const char* dir_a, const char* dir_b, const char* pfx, char** names_out,
+                         size_t* count)
+{
+    if (!c || !dir_a || !dir_b || !names_out || !count) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    *names_out = nullptr;
+    *count = 0;
+    std::vector<std::string> names;
+    if (DIR* d = opendir(dir_a)) { // filepath.Glob(dirA/*): every entry (leading dots too), sorted; errors ignored
+        while (struct dirent* de = readdir(d))
+            if (strcmp(de->d_name, ".") && strcmp(de->d_name, "..")) names.emplace_back(de->d_name);
+        closedir(d);
+    }
+    std::sort(names.begin(), names.end());
+    std::vector<std::string> pa, pb, cand;
+    for (const std::string& nm : names) {
+        const std::string fa = std::string(dir_a) + "/" + nm, fb = std::string(dir_b) + "/" + nm;
+        struct stat st;
+        if (stat(fa.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) continue; // IsDirectory(fileA): subdirectories are ignored
+        if (stat(fb.c_str(), &st) != 0) continue;                         // FileExists(fileB)
+        pa.push_back(fa); pb.push_back(fb); cand.push_back(nm);
+    }
+    std::vector<const char*> ca(pa.size()), cb(pb.size());
+    for (size_t i = 0; i < pa.size(); ++i) { ca[i] = pa[i].c_str(); cb[i] = pb[i].c_str(); }
+    std::vector<uint8_t> eq(pa.size());
+    int rc = snaphash_files_equal(c, ca.data(), cb.data(), pa.size(), eq.data());
+    if (rc) return rc;
+    std::string out;
+    size_t k = 0;
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (!eq[i]) { out += pfx ? pfx : ""; out += cand[i]; out.push_back('\0'); ++k; }
+    char* p = (char*)malloc(out.size() + 1);
+    if (!p) return fail(c, SNAPHASH_ENOMEM, "malloc");
+    memcpy(p, out.data(), out.size());
+    p[out.size()] = 0;
+    *names_out = p;
+    *count = k;
+    return SNAPHASH_OK;
+}
 
 // ---- host-side pieces ------------------------------------------------------------------
 

@@ -26,3 +26,15 @@ def Sha512sumBatch(paths, ctx=None):
 def Sha512sum(infile, ctx=None):
     """Sha512sum returns the sha512 of the given file as a hexdigest."""
     return Sha512sumBatch([infile], ctx)[0]
+
+
+def FilesAreEqual(a, b, ctx=None):
+    """FilesAreEqual compares the two files' contents and returns whether they are the same
+    (reference helpers/cmp.go:31-60); the bytes are compared on the GPU."""
+    return (ctx or default_context()).files_equal([(a, b)])[0]
+
+
+def DirUpdated(dirA, dirB, pfx, ctx=None):
+    """DirUpdated compares two directories, and returns which files present in both have been
+    updated, with the given prefix prepended.  Subdirectories are ignored (helpers/cmp.go:88-114)."""
+    return (ctx or default_context()).dir_updated(dirA, dirB, pfx)

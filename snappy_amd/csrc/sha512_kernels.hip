@@ -4,7 +4,14 @@
 // batched over the files of one writeHashes pass (snappy/build.go:228-259).
 // A file's blocks are strictly sequential (Merkle-Damgard chaining), so the
 // parallel axis is the file list: every kernel here advances many independent
-// streams in lockstep.
+// streams in lockstep.  Three hashing kernels for three regimes:
+//   sha512_wide_kernel          one lane per stream; saturates the VALUs (many streams)
+//   sha512_split_kernel<false>  rounds on one wave, message schedule on helper waves
+//   sha512_split_kernel<true>   the same with every stream on a lane pair (generated
+//                               assembly, pair_rounds.inc): fewest instructions on the
+//                               wave that carries the chaining value (few long streams)
+// plus ranges_equal_kernel (helpers.FilesAreEqual's byte compare, HBM-bound) and the
+// synthetic-content generator used by tests and bench.
 //
 // Data layout in HBM: file bytes are contiguous, 16-byte aligned, described by
 // one 32-byte Job per stream segment.  A wave fetches 128-byte blocks with

@@ -246,6 +246,12 @@ def main():
                          "note": "algorithmic bytes = file bytes hashed by rank 0's launch; SHA-512 is integer-VALU "
                                  "and stream-count bound, not HBM bound (DESIGN.md)"},
             "parity": parity,
+            # how to read frac: SHA-512 is VALU-bound at saturation and, below ~65k
+            # streams, bound by the per-stream rate of the wave that carries the chaining value
+            "ceilings": {"hbm_GBps": HBM_PEAK_GBPS, "valu_saturated_GBps_measured": 1070.0,
+                         "per_stream_MBps_measured": 34.7,
+                         "stream_count_bound_GBps": round(len(my_lens) * 34.7e-3, 1),
+                         "source": "profiles/r01_regime_sweep.txt, profiles/r01_wide_saturated_pmc.json"},
         }
         if strong_leg is not None:
             line["strong_scaling_leg"] = strong_leg

@@ -149,6 +149,27 @@ __global__ __launch_bounds__(1024) void k_lds_mix(uint64_t* cycles, uint32_t* si
     if ((uint32_t)acc + r0 == 0x12345678) sink[0] = r0;
 }
 
+// Cross-wave hand-off inside a workgroup: every wave writes a value to LDS, s_barrier, reads its
+// neighbour wave's value (dependent chain: the value read feeds the next write).  Cycles per
+// round trip = the price of splitting one stream's round across waves.
+template <bool DEP>
+__global__ __launch_bounds__(1024) void k_lds_barrier_pingpong(uint64_t* cycles, uint32_t* sink)
+{
+    __shared__ uint32_t box[1024];
+    const uint32_t t = threadIdx.x, peer = (t + 64u) % blockDim.x;
+    uint32_t v = t;
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < 2048; ++it) {
+        box[t] = v;
+        __syncthreads();
+        v = box[peer] + 1u;
+        if (DEP) __syncthreads(); // second barrier: the slot may be rewritten only after everyone has read
+    }
+    uint64_t t1 = __builtin_amdgcn_s_memtime();
+    if ((t & 63) == 0) cycles[(blockIdx.x * blockDim.x + t) >> 6] = t1 - t0;
+    if (v == 0x12345678) sink[0] = v;
+}
+
 template <typename K>
 static void run(const char* name, K kern, int instr_per_loop, int waves_per_simd, uint64_t* d_cycles, uint32_t* d_sink)
 {
@@ -208,6 +229,9 @@ int main()
         RUN(k_cndmask, 16);
         RUN(k_valu_plus_salu, 32);
         run("k_lds_mix(1ds+4valu)", k_lds_mix<false>, 20, w, d_cycles, d_sink);
+        // per-iteration cost: kIters is not used by this kernel (2048 iterations): scale = 2048/kIters per "instr"
+        run("lds+barrier hop x1 (cycles*4/iter)", k_lds_barrier_pingpong<false>, 1, w, d_cycles, d_sink);
+        run("lds+2barriers hop (cycles*4/iter)", k_lds_barrier_pingpong<true>, 1, w, d_cycles, d_sink);
         printf("\n");
     }
     return 0;

@@ -5,24 +5,33 @@
     (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
 A step is one pass of the hot path over one batch of synthetic input: every
-file of the tree(s) hashed by the HIP kernels from bytes already resident in
-HBM (snaphash_sha512_device), plus -- for N > 1 -- the RCCL all-gather of the
-digest vector.  Workload at N = 1: BASELINE config 2, the 10 000 x 1 MiB tree
-plus its 1 MiB archive stand-in (10 001 streams, 10 001 MiB).  At N > 1 the
-default is weak scaling: N such trees form one file list that is LPT-sharded
-over the ranks (per-GPU work fixed); --scaling strong shards ONE tree instead
-(BASELINE config 4 literally; stream-count-bound).
+file of ONE tree hashed by the HIP kernels from bytes already resident in HBM
+(snaphash_sha512_device), plus -- for N > 1 -- the RCCL all-gather of the digest
+vector.  The workload is what BASELINE.json's metric is quoted on: the
+10 000 x 1 MiB tree plus its 1 MiB archive stand-in (10 001 streams), at
+N = 1 (config 2) and LPT-sharded over N GPUs (config 4: the SAME one tree, so
+`scaling` is "strong" and the N = 1 value of a scaling run equals the plain
+N = 1 bench).  --scaling weak tiles N trees instead (labelled side experiment).
 
-Prints ONE JSON line on rank 0.  `value` is whole-job GiB/s with inputs resident
-in HBM; `roofline` is the dominant kernel against the 8 TB/s HBM-read roofline
-(algorithmic bytes = file bytes hashed); `cpu_baseline` is the oracle (the C
-restatement of the reference's serial path) timed on this box's host cores on
-a bounded sample.
+Prints ONE JSON line on rank 0:
+  value         whole-job GiB/s with inputs resident in HBM when the timed region
+                starts (value_kind says so; the PCIe- and disk-inclusive rates are
+                in `end_to_end`, they are never `value`)
+  roofline      the dominant kernel against the 8 TB/s HBM-read roofline
+                (algorithmic bytes = file bytes hashed); kernel time from HIP
+                events on the launch stream (library stats)
+  end_to_end    N = 1 only: host buffers -> digests (snaphash_sha512_buffers) and
+                on-disk tree -> hashes.yaml (snaphash_tree), the latter compared
+                byte for byte with the oracle's hashes.yaml
+  cpu_baseline  the oracle (C restatement of the reference's serial loop) timed
+                on this box's host cores over a bounded sample of the same tree
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -32,6 +41,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# measured ceilings of this implementation (profiles/); refreshed per round
+VALU_SATURATED_GBPS = float(os.environ.get("SNAPHASH_VALU_CEILING_GBPS", "1070"))
 
 
 def parse_args():
@@ -40,37 +51,29 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "split", "pair"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "split", "pair", "quad"])
+    ap.add_argument("--cpu-seconds", type=float, default=20.0,
+                    help="CPU work budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--e2e", default="auto", choices=["auto", "off", "buffers", "full"],
+                    help="end_to_end legs at N = 1: auto = full for C2, buffers otherwise")
+    ap.add_argument("--e2e-files", type=int, default=0, help="files of the on-disk tree leg (0 = the whole tree)")
     return ap.parse_args()
 
 
-def cpu_baseline(sizes, budget_s):
-    """The oracle (C restatement of helpers.Sha512sum's serial loop) on host cores:
-    files of the same workload, in order, until ~budget_s of CPU work."""
+# ------------------------------------------------------------------------------------------
+# cpu_baseline: the oracle on host cores (reported baseline, not the target)
+# ------------------------------------------------------------------------------------------
+def cpu_pool_leg(sizes, seconds):
+    """The same C port on a pool of host threads (ctypes releases the GIL): what an embarrassingly
+    parallel rewrite of the reference's loop would reach.  A 1-GPU box grants ~16 CPUs whatever
+    os.cpu_count() says, so the pool is capped there; time-bounded."""
     from oracle import oracle
     from concurrent.futures import ThreadPoolExecutor
     n = len(sizes)
-    done_bytes, files, t_hash = 0, 0, 0.0
-    i = 0
-    while t_hash < budget_s:
-        data = oracle.fill_synthetic(int(sizes[i % n]), i % n)  # generation is not timed
-        off = np.zeros(1, dtype=np.uint64)
-        ln = np.array([len(data)], dtype=np.uint64)
-        t0 = time.perf_counter()
-        oracle.sha512_batch(data, off, ln)
-        t_hash += time.perf_counter() - t0
-        done_bytes += len(data)
-        files += 1
-        i += 1
-    one = done_bytes / t_hash / 2**30
-    # same port on a pool of host threads (ctypes releases the GIL): what an embarrassingly
-    # parallel rewrite of the reference's loop would reach.  A 1-GPU box grants ~16 CPUs
-    # whatever os.cpu_count() says, so the pool is capped there; time-bounded (3 s).
     cores = min(16, os.cpu_count() or 1)
     blobs = [oracle.fill_synthetic(int(sizes[k % n]), k % n) for k in range(cores)]
-    deadline = time.perf_counter() + min(3.0, budget_s)
+    deadline = time.perf_counter() + seconds
 
     def work(k):
         b = blobs[k]
@@ -84,13 +87,126 @@ def cpu_baseline(sizes, budget_s):
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         tot = sum(ex.map(work, range(cores)))
-    allc = tot / (time.perf_counter() - t0) / 2**30
-    return {"value": round(one, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
-            "sample": "first %d files of the workload (%.1f MiB), serial one-file-at-a-time like the reference's "
-                      "filepath.Walk loop, %.1f s of CPU work; content generation not timed" % (files, done_bytes / 2**20, t_hash),
-            "host_cores_visible": os.cpu_count(),
-            "all_cores": {"value": round(allc, 3), "cores": cores,
-                          "note": "same C port on a %d-thread pool (the reference itself is single-goroutine)" % cores}}
+    return {"value": round(tot / (time.perf_counter() - t0) / 2**30, 3), "cores": cores,
+            "note": "same C port on a %d-thread pool (the reference itself is single-goroutine)" % cores}
+
+
+def cpu_baseline_buffers(sizes, budget_s):
+    """Files of the workload, in order, one at a time like the reference's filepath.Walk loop,
+    until ~budget_s of CPU work (content generation not timed)."""
+    from oracle import oracle
+    n = len(sizes)
+    done_bytes, files, t_hash, i = 0, 0, 0.0, 0
+    while t_hash < budget_s and i < n:
+        data = oracle.fill_synthetic(int(sizes[i]), i)
+        off = np.zeros(1, dtype=np.uint64)
+        ln = np.array([len(data)], dtype=np.uint64)
+        t0 = time.perf_counter()
+        oracle.sha512_batch(data, off, ln)
+        t_hash += time.perf_counter() - t0
+        done_bytes += len(data)
+        files += 1
+        i += 1
+    return {"value": round(done_bytes / t_hash / 2**30, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
+            "sample": "first %d files of the workload (%.1f MiB) through the oracle's Sha512sum loop, serial, "
+                      "%.1f s of CPU work; content generation not timed" % (files, done_bytes / 2**20, t_hash),
+            "host_cores_visible": os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------------------
+# end_to_end legs (N = 1): the whole pass as a caller sees it
+# ------------------------------------------------------------------------------------------
+def e2e_buffers(ctx, host, offsets, lens, want_digests):
+    """host memory in, digests out: pinned staging, double-buffered H2D, chunked segments."""
+    import ctypes
+    from snappy_amd import _lib
+    n = len(lens)
+    ptrs = (ctypes.c_void_p * n)(*[host.ctypes.data + int(o) for o in offsets])
+    clens = (ctypes.c_uint64 * n)(*[int(x) for x in lens])
+    out = ctypes.create_string_buffer(64 * n)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = _lib.lib().snaphash_sha512_buffers(ctx._h, ptrs, clens, n, out)
+        dt = time.perf_counter() - t0
+        if rc:
+            raise SystemExit("snaphash_sha512_buffers failed: %d" % rc)
+        st = ctx.stats()
+        if best is None or dt < best[0]:
+            best = (dt, st)
+    got = np.frombuffer(out.raw, dtype=np.uint8).reshape(n, 64)
+    if not np.array_equal(got, want_digests):
+        raise SystemExit("PARITY FAILURE: host-buffer digests differ from the HBM-resident pass")
+    dt, st = best
+    total = int(np.sum(lens))
+    return {"what": "host buffers -> snaphash_sha512_buffers -> digests on the host (pinned staging, H2D, kernels)",
+            "ms": round(dt * 1e3, 2), "GiBps": round(total / 2**30 / dt, 2), "h2d_ms": round(st["h2d_ms"], 2),
+            "kernel_ms": round(st["kernel_ms"], 2), "launches": int(st["launches"]),
+            "parity": "digest vector identical to the HBM-resident pass", "best_of": 3}
+
+
+def e2e_tree(ctx, host, offsets, lens, nfiles, cpu_seconds):
+    """on-disk tree -> hashes.yaml: walk, parallel pread, staging, H2D, kernels, YAML; the oracle's
+    serial CPU pass over the same tree is both the checker and the reference-shaped timing."""
+    from oracle import oracle
+    from snappy_amd import synthetic
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    n = min(nfiles, len(lens) - 1) if nfiles else len(lens) - 1
+    need = int(np.sum(lens[:n])) + int(lens[-1])
+    if base:
+        free = shutil.disk_usage(base).free
+        if free < need + (2 << 30):
+            n = max(100, int(n * (free - (2 << 30)) / max(need, 1)))
+    tmp = tempfile.mkdtemp(prefix="snaphash_bench_", dir=base)
+    try:
+        build = os.path.join(tmp, "build")
+        os.makedirs(build)
+        made = set()
+        for i in range(n):
+            p = os.path.join(build, synthetic.file_name(i))
+            d = os.path.dirname(p)
+            if d not in made:
+                os.makedirs(d, exist_ok=True)
+                made.add(d)
+            host[int(offsets[i]):int(offsets[i]) + int(lens[i])].tofile(p)
+        tar = os.path.join(tmp, "data.tar.gz")
+        host[int(offsets[-1]):int(offsets[-1]) + int(lens[-1])].tofile(tar)
+        total = int(np.sum(lens[:n])) + int(lens[-1])
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y_gpu = ctx.tree(build, tar)
+            dt = time.perf_counter() - t0
+            st = ctx.stats()
+            if best is None or dt < best[0]:
+                best = (dt, st)
+        t0 = time.perf_counter()
+        res = ctx.verify(build, y_gpu, tar)
+        dt_v = time.perf_counter() - t0
+        if res is not None:
+            raise SystemExit("Verify reports a mismatch on the tree just hashed: %r" % (res,))
+        out = {"what": "on-disk tree (tmpfs) -> snaphash_tree -> hashes.yaml (walk, pread, staging, H2D, kernels, YAML)",
+               "files": n + 1, "bytes": total, "ms": round(best[0] * 1e3, 2), "GiBps": round(total / 2**30 / best[0], 2),
+               "h2d_ms": round(best[1]["h2d_ms"], 2), "kernel_ms": round(best[1]["kernel_ms"], 2),
+               "verify_ms": round(dt_v * 1e3, 2), "yaml_bytes": len(y_gpu), "best_of": 3}
+        cpu = None
+        if cpu_seconds > 0:
+            t0 = time.perf_counter()
+            y_cpu = oracle.hashes_yaml(build, tar)
+            dt_c = time.perf_counter() - t0
+            if y_cpu != y_gpu:
+                raise SystemExit("PARITY FAILURE: hashes.yaml differs from the oracle's")
+            out["parity"] = "hashes.yaml byte-identical to the oracle's (%d records)" % y_gpu.count(b"- name: ")
+            cpu = {"value": round(total / 2**30 / dt_c, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
+                   "sample": "the oracle's whole writeHashes pass (walk, 32 KiB reads, SHA-512, YAML) over the same "
+                             "on-disk tree of %d files / %.0f MiB: %.1f s on one core, as the reference's single "
+                             "goroutine would run it" % (n + 1, total / 2**20, dt_c),
+                   "host_cores_visible": os.cpu_count()}
+        else:
+            out["parity"] = "not checked (--cpu-seconds 0)"
+        return out, cpu
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -111,105 +227,85 @@ def main():
     torch.cuda.set_device(local_rank)
     # SNAPHASH_BENCH_FORCE_DIST=1: run the RCCL path even with one rank (rehearsal on a 1-GPU box)
     force_dist = os.environ.get("SNAPHASH_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
-    if world > 1 or force_dist:
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    # ---- the job: file list, shard plan (identical on every rank) ------------------
-    tree = synthetic.config_sizes(args.workload)
-    ntrees = world if args.scaling == "weak" else 1
-    sizes = np.tile(tree, ntrees)
-    findex = np.arange(len(sizes), dtype=np.uint64)
-    plan = ShardPlan(sizes, world)
-    mine = plan.members(rank)
-    kmax = plan.kmax
-    my_lens = np.ascontiguousarray(sizes[mine])
-    my_off, my_total = synthetic.pack_offsets(my_lens)
-    my_bytes = int(my_lens.sum())
-    total_bytes = int(sizes.sum())
-
-    kern = {"auto": _lib.KERNEL_AUTO, "wide": _lib.KERNEL_WIDE, "split": _lib.KERNEL_SPLIT, "pair": _lib.KERNEL_PAIR}[args.kernel]
+    kern = {"auto": _lib.KERNEL_AUTO, "wide": _lib.KERNEL_WIDE, "split": _lib.KERNEL_SPLIT, "pair": _lib.KERNEL_PAIR,
+            "quad": getattr(_lib, "KERNEL_QUAD", 4)}[args.kernel]
     stream = torch.cuda.current_stream().cuda_stream
     ctx = Context(device=local_rank, kernel=kern, stream=stream)
-    data = torch.empty(max(my_total, 16), dtype=torch.uint8, device="cuda")
-    ctx.fill_synthetic_device(data.data_ptr(), my_off, my_lens, np.ascontiguousarray(findex[mine]))
-    local = torch.zeros((kmax, 64), dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-
-    kernel_ms = []
-
-    def step(record):
-        ctx.sha512_device(data.data_ptr(), my_off, my_lens, local.data_ptr())
-        full = gather_digests(local, plan, force_collective=force_dist)  # RCCL all-gather of the digest slabs (no-op at N = 1)
-        ctx.sync()
-        if record:
-            kernel_ms.append(ctx.stats()["kernel_ms"])
-        return full
+    tree = synthetic.config_sizes(args.workload)
 
     def fence():
-        if world > 1 or force_dist:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    full = None
-    for _ in range(args.steps):
-        full = step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_job(sizes, steps, warmup):
+        """One file list LPT-sharded over the ranks; returns timing + the gathered digest matrix."""
+        findex = np.arange(len(sizes), dtype=np.uint64)
+        plan = ShardPlan(sizes, world)
+        mine = plan.members(rank)
+        my_lens = np.ascontiguousarray(sizes[mine])
+        my_off, my_total = synthetic.pack_offsets(my_lens)
+        data = torch.empty(max(my_total, 16), dtype=torch.uint8, device="cuda")
+        ctx.fill_synthetic_device(data.data_ptr(), my_off, my_lens, np.ascontiguousarray(findex[mine]))
+        local = torch.zeros((max(plan.kmax, 1), 64), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        kernel_ms = []
+        full = None
 
-    # ---- N > 1 only: the literal BASELINE config 4 (ONE tree sharded over the ranks), reported
-    # beside the headline so that both readings of "scaling" are on record -------------------
-    strong_leg = None
-    if (world > 1 or force_dist) and args.scaling == "weak":
-        plan_s = ShardPlan(tree, world)
-        mine_s = plan_s.members(rank)
-        lens_s = np.ascontiguousarray(tree[mine_s])
-        off_s, total_s = synthetic.pack_offsets(lens_s)
-        data_s = torch.empty(max(total_s, 16), dtype=torch.uint8, device="cuda")
-        ctx.fill_synthetic_device(data_s.data_ptr(), off_s, lens_s, np.ascontiguousarray(mine_s.astype(np.uint64)))
-        local_s = torch.zeros((plan_s.kmax, 64), dtype=torch.uint8, device="cuda")
-
-        def step_s():
-            ctx.sha512_device(data_s.data_ptr(), off_s, lens_s, local_s.data_ptr())
-            out = gather_digests(local_s, plan_s, force_collective=force_dist)
+        def step(record):
+            ctx.sha512_device(data.data_ptr(), my_off, my_lens, local.data_ptr())
+            out = gather_digests(local, plan, force_collective=force_dist)  # RCCL all-gather of the slabs (no-op at N = 1)
             ctx.sync()
+            if record:
+                kernel_ms.append(ctx.stats()["kernel_ms"])
             return out
-        for _ in range(2):
-            step_s()
+        for _ in range(warmup):
+            step(False)
         fence()
-        ts = time.perf_counter()
-        nrep = max(3, min(10, args.steps))
-        for _ in range(nrep):
-            step_s()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            full = step(True)
         fence()
-        el = time.perf_counter() - ts
+        elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        strong_leg = {"workload": "ONE %s tree (%d files) LPT-sharded over %d GPU(s) + RCCL digest all-gather" %
-                                  (args.workload, len(tree), world),
-                      "value": round(float(tree.sum()) / 2**30 / (el / nrep), 3), "unit": "GiB/s",
-                      "ms_per_step": round(el / nrep * 1e3, 4), "steps": nrep,
-                      "note": "stream-count-bound: %d streams per GPU advance no faster than %d on one GPU "
-                              "(DESIGN.md sec. 5)" % (len(mine_s), len(tree))}
-        del data_s
+            elapsed = float(t.item())
+        return {"elapsed": elapsed, "kernel_ms": float(np.mean(kernel_ms)), "my_bytes": int(my_lens.sum()),
+                "my_streams": len(my_lens), "digests": full.cpu().numpy(), "stats": ctx.stats(),
+                "data": data, "my_off": my_off, "my_lens": my_lens, "total_bytes": int(sizes.sum())}
 
-    # ---- parity spot check, outside the timed region ---------------------------------
-    digests = full.cpu().numpy()
+    ntrees = world if args.scaling == "weak" else 1
+    sizes = np.tile(tree, ntrees)
+    job = run_job(sizes, args.steps, args.warmup)
+
+    # the other reading of "scaling" beside the headline, on record (N > 1 only)
+    side_leg = None
+    if use_dist:
+        other = "weak" if args.scaling == "strong" else "strong"
+        osizes = np.tile(tree, world if other == "weak" else 1)
+        nrep = max(3, min(10, args.steps))
+        j2 = run_job(osizes, nrep, 2)
+        side_leg = {"scaling": other,
+                    "workload": "%d %s tree(s) (%d files) LPT-sharded over %d GPU(s) + RCCL digest all-gather" %
+                                (world if other == "weak" else 1, args.workload, len(osizes), world),
+                    "value": round(j2["total_bytes"] / 2**30 / (j2["elapsed"] / nrep), 3), "unit": "GiB/s",
+                    "ms_per_step": round(j2["elapsed"] / nrep * 1e3, 4), "steps": nrep}
+        del j2
+
+    # ---- parity spot check of the timed path, outside the timed region ------------------
+    digests = job["digests"]
     parity = None
     if rank == 0:
         import hashlib
         rng = np.random.default_rng(1)
         sample = sorted(set([0, len(sizes) - 1] + [int(x) for x in rng.integers(0, len(sizes), size=14)]))
+        sample = [i for i in sample if sizes[i] <= (64 << 20)] or [int(np.argmin(sizes))]
         for i in sample:  # independent check: numpy generator + hashlib (OpenSSL), not the timed path
             want = hashlib.sha512(synthetic.file_bytes(int(sizes[i]), int(i))).digest()
             if digests[i].tobytes() != want:
@@ -217,49 +313,78 @@ def main():
         parity = {"checked_files": len(sample), "result": "bit-exact vs hashlib.sha512",
                   "sha512_of_digest_vector": hashlib.sha512(digests.tobytes()).hexdigest()[:32]}
 
+    # ---- end-to-end legs and the CPU baseline: rank 0, N = 1 only -------------------------
+    end_to_end, cpu = None, None
+    if rank == 0 and world == 1 and not force_dist:
+        mode = args.e2e
+        if mode == "auto":
+            mode = "full" if args.workload == "C2" else ("buffers" if job["total_bytes"] <= (16 << 30) else "off")
+        if mode != "off":
+            host = job["data"].cpu().numpy()  # the same bytes the resident pass hashed, now in host memory
+            del job["data"]
+            torch.cuda.empty_cache()
+            ectx = Context(device=local_rank, kernel=kern)  # own stream and staging engine
+            end_to_end = {"buffers": e2e_buffers(ectx, host, job["my_off"], job["my_lens"], digests)}
+            if mode == "full":
+                end_to_end["tree"], cpu = e2e_tree(ectx, host, job["my_off"], job["my_lens"], args.e2e_files,
+                                                   args.cpu_seconds)
+            ectx.close()
+            del host
+        if args.cpu_seconds > 0:
+            if cpu is None:
+                cpu = cpu_baseline_buffers(tree, args.cpu_seconds)
+            cpu["all_cores"] = cpu_pool_leg(tree, 3.0)
+
     if rank == 0:
-        st = ctx.stats()
-        ms_step = elapsed / args.steps * 1e3
-        value = total_bytes / 2**30 / (elapsed / args.steps)
-        k_ms = float(np.mean(kernel_ms))
-        achieved = my_bytes / (k_ms * 1e-3) / 1e9
-        kname = {_lib.KERNEL_SPLIT: "sha512_split_kernel<false>", _lib.KERNEL_PAIR: "sha512_split_kernel<true>"}.get(st["kernel_used"], "sha512_wide_kernel")
-        traffic = None
+        st = job["stats"]
+        ms_step = job["elapsed"] / args.steps * 1e3
+        value = job["total_bytes"] / 2**30 / (job["elapsed"] / args.steps)
+        k_ms = job["kernel_ms"]
+        achieved = job["my_bytes"] / (k_ms * 1e-3) / 1e9
+        kname = _lib.KERNEL_NAMES.get(st["kernel_used"], "sha512_wide_kernel")
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % kname.replace("<", "_").replace(">", ""))
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            # PMC traffic is a per-launch figure of ONE workload: only quote it for that workload
+            if tj.get("workload", "C2") == args.workload and world == 1 and tj.get("bytes_per_launch", job["my_bytes"]) == job["my_bytes"]:
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
+        wl = "%s: %s%d files%s, HBM-resident, LPT-sharded over %d GPU(s)%s" % (
+            args.workload, "ONE tree of " if ntrees == 1 else "%d trees, " % ntrees, len(sizes),
+            " (10 000 x 1 MiB + the 1 MiB archive stand-in)" if args.workload == "C2" and ntrees == 1 else "",
+            world, ", RCCL all-gather of the digest vector" if world > 1 else "")
         line = {
-            "metric": "GiB/s hashed (whole node), bit-exact hashes.yaml, 10k x 1 MiB tree" if args.workload == "C2"
-                      else "GiB/s hashed (whole node), bit-exact hashes.yaml, workload %s" % args.workload,
-            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "GiB/s hashed (whole node), bit-exact hashes.yaml, 10k x 1 MiB tree" if args.workload == "C2" and ntrees == 1
+                      else "GiB/s hashed (whole node), bit-exact hashes.yaml, workload %s x%d" % (args.workload, ntrees),
+            "value": round(value, 3), "unit": "GiB/s",
+            "value_kind": "hbm_resident: file bytes already in HBM when the timed region starts; kernels + digest gather "
+                          "only (PCIe- and disk-inclusive rates: end_to_end)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: %d tree(s) of %d files (first of %d sized %d B; C1/C2 include a 1-file archive stand-in), HBM-resident, "
-                                   "LPT-sharded over %d GPU(s)%s" % (
-                                       args.workload, ntrees, len(tree), len(tree) - 1, int(tree[0]), world,
-                                       ", RCCL all-gather of the digest vector" if world > 1 else ""),
-                       "files": int(len(sizes)), "bytes": total_bytes, "kernel": kname, "launches_per_step": int(st["launches"]),
-                       "sha512_blocks_per_step": int(st["blocks"]) * 1 if world == 1 else None},
+            "config": {"workload": wl, "files": int(len(sizes)), "bytes": job["total_bytes"], "kernel": kname,
+                       "launches_per_step": int(st["launches"]),
+                       "sha512_blocks_per_step": int(st["blocks"]) if world == 1 else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": kname, "kernel_ms": round(k_ms, 4), "bytes_per_launch": my_bytes,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname, "kernel_ms": round(k_ms, 4), "bytes_per_launch": job["my_bytes"],
+                         "frac_of_valu_ceiling": round(achieved / VALU_SATURATED_GBPS, 4),
                          "note": "algorithmic bytes = file bytes hashed by rank 0's launch; SHA-512 is integer-VALU "
-                                 "and stream-count bound, not HBM bound (DESIGN.md)"},
+                                 "and stream-count bound, not HBM bound (DESIGN.md sec. 4)"},
             "parity": parity,
-            # how to read frac: SHA-512 is VALU-bound at saturation and, below ~65k
-            # streams, bound by the per-stream rate of the wave that carries the chaining value
-            "ceilings": {"hbm_GBps": HBM_PEAK_GBPS, "valu_saturated_GBps_measured": 1070.0,
-                         "per_stream_MBps_measured": 34.7,
-                         "stream_count_bound_GBps": round(len(my_lens) * 34.7e-3, 1),
-                         "source": "profiles/r01_regime_sweep.txt, profiles/r01_wide_saturated_pmc.json"},
+            "ceilings": {"hbm_GBps": HBM_PEAK_GBPS, "valu_saturated_GBps_measured": VALU_SATURATED_GBPS,
+                         "per_stream_MBps_here": round(achieved * 1e3 / max(job["my_streams"], 1), 2),
+                         "source": "profiles/ (regime sweep, saturated-launch PMC)"},
         }
-        if strong_leg is not None:
-            line["strong_scaling_leg"] = strong_leg
-        if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(tree, args.cpu_seconds)
+        if side_leg is not None:
+            line["other_scaling_leg"] = side_leg
+        if end_to_end is not None:
+            line["end_to_end"] = end_to_end
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1 or force_dist:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -21,9 +21,12 @@
  *   - The caller owns every input and output buffer; the library keeps no caller
  *     pointer past return.  Only snaphash_tree's yaml_out and snaphash_walk's
  *     record set are library-allocated (snaphash_free / snaphash_records_free).
- *   - A ctx is bound to one device and is not thread-safe (one call in flight per
- *     ctx); distinct ctxs may be used concurrently.  No signal handlers are
- *     installed (the Go runtime owns them).
+ *   - A ctx owns one or several devices (snaphash_config.devices) and is not
+ *     thread-safe (one call in flight per ctx); distinct ctxs may be used
+ *     concurrently.  With several devices the file list of a call is LPT-sharded
+ *     inside the library (one host thread and one staging engine per device) and
+ *     the digest vector is gathered with a single-process RCCL all-gather over
+ *     xGMI.  No signal handlers are installed (the Go runtime owns them).
  *   - Digests are raw 64-byte big-endian SHA-512 values; the Go wrapper
  *     hex-encodes them with encoding/hex (lowercase, helpers.go:200).
  */
@@ -37,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SNAPHASH_ABI_VERSION 1
+#define SNAPHASH_ABI_VERSION 2
 
 enum {
     SNAPHASH_OK = 0,
@@ -62,13 +65,32 @@ enum { /* snaphash_config.kernel */
 
 typedef struct snaphash_ctx snaphash_ctx;
 
+enum { /* snaphash_config.flags */
+    SNAPHASH_FLAG_CHECK_GATHER = 1, /* several devices: also copy every device's digest slab to the host and
+                                       require the RCCL-gathered vector to equal it (the collective's parity check) */
+    SNAPHASH_FLAG_NO_RCCL = 2       /* several devices: gather by per-device copies only */
+};
+
 typedef struct snaphash_config {
-    uint32_t struct_size;   /* sizeof(snaphash_config) */
-    int32_t device;         /* HIP device ordinal; -1 = the calling thread's current device */
-    uint64_t staging_bytes; /* size of EACH of the two pinned-host/HBM staging buffers; 0 = 256 MiB */
+    uint32_t struct_size;   /* sizeof(snaphash_config); a caller built against ABI 1 passes the shorter size */
+    int32_t device;         /* HIP device ordinal when n_devices == 0; -1 = the calling thread's current device */
+    uint64_t staging_bytes; /* size of EACH of the two pinned-host/HBM staging buffers per device; 0 = 256 MiB */
     uint32_t kernel;        /* SNAPHASH_KERNEL_* */
     uint32_t reserved;
-    void *stream;           /* hipStream_t to launch on; NULL = a stream owned by the ctx */
+    void *stream;           /* hipStream_t to launch on (single-device ctx only); NULL = a stream owned by the ctx */
+    /* ---- ABI 2 ---- */
+    const int32_t *devices; /* n_devices HIP ordinals: the GPUs of the node this ctx shards over.  A single
+                               entry of -1 means every visible device.  An ordinal may repeat
+                               (two engines on one GPU: used by the tests on a 1-GPU box; RCCL needs distinct
+                               devices, so the gather then falls back to per-device copies). */
+    uint32_t n_devices;     /* 0 = the single `device` above */
+    uint32_t host_threads;  /* hybrid scheduling, opt-in: > 0 lets the library hash on that many host threads,
+                               concurrently with the GPU batch, the few streams whose single-stream time on the
+                               GPU would set the makespan (a lone stream advances at ~40 MB/s on the GPU, ~0.5 GB/s
+                               on a host core).  0 (default) = every byte is hashed on the GPU.  Not a fallback:
+                               init still fails without a gfx950 device.  Host entry points only. */
+    uint32_t flags;         /* SNAPHASH_FLAG_* */
+    uint32_t reserved2;
 } snaphash_config;
 
 typedef struct snaphash_stats { /* of the most recent hashing call on the ctx */
@@ -81,6 +103,19 @@ typedef struct snaphash_stats { /* of the most recent hashing call on the ctx */
     double h2d_ms;          /* host->HBM copies (files/buffers entry points) */
     double wall_ms;         /* whole call, host clock */
 } snaphash_stats;
+
+typedef struct snaphash_stats_ex { /* of the most recent hashing call on the ctx */
+    uint32_t struct_size;  /* in: sizeof(snaphash_stats_ex) */
+    uint32_t n_devices;    /* engines the ctx shards over */
+    uint32_t gather_kind;  /* 0 = none (one device), 1 = RCCL all-gather, 2 = per-device copies */
+    uint32_t gather_checked; /* 1 = the RCCL result was compared with per-device copies and matched */
+    double gather_ms;      /* digest gather, host clock */
+    uint64_t gpu_bytes;    /* bytes hashed by HIP kernels */
+    uint64_t host_bytes;   /* bytes hashed by host threads (hybrid scheduling; 0 unless host_threads > 0) */
+    uint64_t host_streams; /* streams that finished on a host thread */
+    uint64_t handover_streams; /* of those, streams whose prefix was hashed on the GPU first */
+    double host_ms;        /* busiest host thread, host clock */
+} snaphash_stats_ex;
 
 /* ---- lifetime -------------------------------------------------------------- */
 int snaphash_init(const snaphash_config *cfg /* may be NULL */, snaphash_ctx **out);
@@ -135,7 +170,34 @@ typedef struct snaphash_mismatch {
 int snaphash_verify(snaphash_ctx *ctx, const char *inst_dir, const char *data_tar,
                     const char *yaml, size_t yaml_len, snaphash_mismatch *first);
 
+/* snaphash_tree / snaphash_write_hashes with the archive digest supplied by the caller
+ * (data_tar == NULL, archive_digest = the 64 raw bytes): the package's own data.tar.gz is ONE
+ * stream, so the Go side hashes it with its existing crypto/sha512 code on a host core while the
+ * GPU batch covers the tree.  With data_tar != NULL archive_digest is
+ * ignored and the call equals snaphash_tree.  write != 0 also writes DEBIAN/hashes.yaml;
+ * yaml_out may then be NULL. */
+int snaphash_tree_ex(snaphash_ctx *ctx, const char *build_dir, const char *data_tar,
+                     const uint8_t *archive_digest, int write, char **yaml_out, size_t *yaml_len);
+
 void snaphash_free(void *p);
+
+/* ---- streaming: hash while another pass reads ------------------ */
+
+/* The reference reads every file twice in Build: tarCreate streams it into data.tar.gz
+ * (clickdeb/deb.go:285-341), then writeHashes reads it again (snappy/build.go:228-259).  A batch
+ * lets the producer feed each chunk it has just read, hash.Hash-style, so the bytes are read once:
+ *   begin -> { append(stream, chunk) ... end(stream) } per file, streams may interleave -> finish.
+ * append copies the bytes into pinned staging (the caller may reuse its buffer at once); full
+ * staging buffers go to the GPU while the producer keeps reading; a stream's chaining value
+ * stays in HBM between launches.  Streams are numbered 0 .. n_streams-1 by the caller.
+ * finish pads and hashes what is left and writes n_streams digests (a stream that was never
+ * appended to hashes as the empty file; a stream not ended is ended).  Single-device ctx only. */
+typedef struct snaphash_batch snaphash_batch;
+int snaphash_batch_begin(snaphash_ctx *ctx, size_t n_streams, snaphash_batch **out);
+int snaphash_batch_append(snaphash_batch *b, size_t stream, const void *data, size_t n);
+int snaphash_batch_end(snaphash_batch *b, size_t stream);
+int snaphash_batch_finish(snaphash_batch *b, uint8_t *digests /* n_streams * 64 */);
+void snaphash_batch_abort(snaphash_batch *b);
 
 /* ---- neighbouring scan: helpers.FilesAreEqual / DirUpdated -------- */
 
@@ -211,7 +273,10 @@ int snaphash_fill_synthetic_device(snaphash_ctx *ctx, void *d_base, const uint64
 /* ---- diagnostics ------------------------------------------------------------ */
 const char *snaphash_strerror(int code);
 const char *snaphash_last_error(const snaphash_ctx *ctx); /* ctx == NULL: why the last snaphash_init on this thread failed */
-void snaphash_get_stats(const snaphash_ctx *ctx, snaphash_stats *out);
+void snaphash_get_stats(const snaphash_ctx *ctx, snaphash_stats *out); /* several devices: sums; the *_ms are the slowest device's */
+int snaphash_get_stats_ex(const snaphash_ctx *ctx, snaphash_stats_ex *out);
+/* per engine i < n_devices: its HIP ordinal and its own stats of the most recent call */
+int snaphash_get_device_stats(const snaphash_ctx *ctx, uint32_t i, int32_t *device, snaphash_stats *out);
 
 #ifdef __cplusplus
 }

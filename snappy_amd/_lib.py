@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("SNAPHASH_LIB") or os.path.join(_HERE, "libsnaphash.so
 
 OK, EINVAL, ENOMEM, EIO, EDEVICE, EMODE, ENAME, EPARSE, EMISMATCH = 0, -1, -2, -3, -4, -5, -6, -7, -8
 KERNEL_AUTO, KERNEL_WIDE, KERNEL_SPLIT, KERNEL_PAIR = 0, 1, 2, 3
+KERNEL_NAMES = {KERNEL_WIDE: "sha512_wide_kernel", KERNEL_SPLIT: "sha512_split_kernel<false>",
+                KERNEL_PAIR: "sha512_split_kernel<true>"}
 
 # every symbol include/snaphash.h declares
 EXPORTS = [
@@ -24,12 +26,25 @@ EXPORTS = [
     "snaphash_walk", "snaphash_records_count", "snaphash_records_get", "snaphash_records_free",
     "snaphash_emit_yaml", "snaphash_parse_yaml", "snaphash_records_sha512_hex", "snaphash_mode_string", "snaphash_mode_parse", "snaphash_lpt_assign",
     "snaphash_fill_synthetic_device", "snaphash_strerror", "snaphash_last_error", "snaphash_get_stats",
+    "snaphash_get_stats_ex", "snaphash_get_device_stats", "snaphash_tree_ex",
+    "snaphash_batch_begin", "snaphash_batch_append", "snaphash_batch_end", "snaphash_batch_finish", "snaphash_batch_abort",
 ]
+FLAG_CHECK_GATHER, FLAG_NO_RCCL = 1, 2
 
 
 class Config(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("staging_bytes", ctypes.c_uint64),
-                ("kernel", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("stream", ctypes.c_void_p)]
+                ("kernel", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("stream", ctypes.c_void_p),
+                # ABI 2
+                ("devices", ctypes.POINTER(ctypes.c_int32)), ("n_devices", ctypes.c_uint32),
+                ("host_threads", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("reserved2", ctypes.c_uint32)]
+
+
+class StatsEx(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("n_devices", ctypes.c_uint32), ("gather_kind", ctypes.c_uint32),
+                ("gather_checked", ctypes.c_uint32), ("gather_ms", ctypes.c_double), ("gpu_bytes", ctypes.c_uint64),
+                ("host_bytes", ctypes.c_uint64), ("host_streams", ctypes.c_uint64), ("handover_streams", ctypes.c_uint64),
+                ("host_ms", ctypes.c_double)]
 
 
 class Stats(ctypes.Structure):
@@ -110,6 +125,16 @@ def lib():
     L.snaphash_last_error.restype = ctypes.c_char_p
     L.snaphash_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     L.snaphash_get_stats.restype = None
+    L.snaphash_get_stats_ex.argtypes = [vp, ctypes.POINTER(StatsEx)]
+    L.snaphash_get_device_stats.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(Stats)]
+    L.snaphash_tree_ex.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int,
+                                   ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.snaphash_batch_begin.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.snaphash_batch_append.argtypes = [vp, sz, vp, sz]
+    L.snaphash_batch_end.argtypes = [vp, sz]
+    L.snaphash_batch_finish.argtypes = [vp, vp]
+    L.snaphash_batch_abort.argtypes = [vp]
+    L.snaphash_batch_abort.restype = None
     _lib = L
     return L
 
@@ -122,10 +147,18 @@ def strerror(code):
 
 
 class Context:
-    """One snaphash_ctx: bound to one GPU, one call in flight at a time."""
+    """One snaphash_ctx: one GPU (device=) or several (devices=[...], [-1] = all visible; the file list of a
+    call is then LPT-sharded inside the library and the digests gathered over RCCL), one call in flight.
+    host_threads > 0 opts into hybrid scheduling (oversize streams finish on host threads)."""
 
-    def __init__(self, device=-1, staging_bytes=0, kernel=KERNEL_AUTO, stream=None):
+    def __init__(self, device=-1, staging_bytes=0, kernel=KERNEL_AUTO, stream=None, devices=None, host_threads=0, flags=0):
         cfg = Config(ctypes.sizeof(Config), device, staging_bytes, kernel, 0, stream)
+        if devices is not None:
+            self._devs = (ctypes.c_int32 * len(devices))(*devices)
+            cfg.devices = ctypes.cast(self._devs, ctypes.POINTER(ctypes.c_int32))
+            cfg.n_devices = len(devices)
+        cfg.host_threads = host_threads
+        cfg.flags = flags
         h = ctypes.c_void_p()
         rc = lib().snaphash_init(ctypes.byref(cfg), ctypes.byref(h))
         if rc:
@@ -200,6 +233,20 @@ class Context:
     def write_hashes(self, build_dir, data_tar):
         self._check(lib().snaphash_write_hashes(self._h, os.fsencode(build_dir), os.fsencode(data_tar)))
 
+    def tree_ex(self, build_dir, data_tar=None, archive_digest=None, write=False):
+        """snaphash_tree_ex: the archive digest may be supplied by the caller (data_tar=None)."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(lib().snaphash_tree_ex(self._h, os.fsencode(build_dir), os.fsencode(data_tar) if data_tar else None,
+                                           archive_digest, 1 if write else 0, ctypes.byref(p), ctypes.byref(n)))
+        try:
+            return ctypes.string_at(p.value, n.value)
+        finally:
+            lib().snaphash_free(p)
+
+    def batch(self, n_streams):
+        """Streaming batch (row f2): feed chunks as another pass reads them."""
+        return Batch(self, n_streams)
+
     def verify(self, inst_dir, yaml_bytes, data_tar=None):
         """-> None when the tree matches, else (kind, name) of the first mismatch."""
         m = Mismatch()
@@ -243,6 +290,49 @@ class Context:
         s = Stats()
         lib().snaphash_get_stats(self._h, ctypes.byref(s))
         return {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+
+    def stats_ex(self):
+        s = StatsEx(ctypes.sizeof(StatsEx))
+        self._check(lib().snaphash_get_stats_ex(self._h, ctypes.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in StatsEx._fields_}
+
+    def device_stats(self, i):
+        s, d = Stats(), ctypes.c_int32()
+        self._check(lib().snaphash_get_device_stats(self._h, i, ctypes.byref(d), ctypes.byref(s)))
+        out = {f[0]: getattr(s, f[0]) for f in Stats._fields_}
+        out["device"] = d.value
+        return out
+
+
+class Batch:
+    """snaphash_batch_*: hash.Hash-style appends into many streams, digests at finish()."""
+
+    def __init__(self, ctx, n_streams):
+        self._ctx, self.n = ctx, n_streams
+        h = ctypes.c_void_p()
+        ctx._check(lib().snaphash_batch_begin(ctx._h, n_streams, ctypes.byref(h)))
+        self._h = h
+
+    def append(self, stream, data):
+        buf = (ctypes.c_char * len(data)).from_buffer_copy(data) if len(data) else None
+        self._ctx._check(lib().snaphash_batch_append(self._h, stream, ctypes.addressof(buf) if buf is not None else None, len(data)))
+
+    def append_ptr(self, stream, addr, n):
+        self._ctx._check(lib().snaphash_batch_append(self._h, stream, addr, n))
+
+    def end(self, stream):
+        self._ctx._check(lib().snaphash_batch_end(self._h, stream))
+
+    def finish(self):
+        out = ctypes.create_string_buffer(64 * max(self.n, 1))
+        h, self._h = self._h, None
+        self._ctx._check(lib().snaphash_batch_finish(h, out))
+        return [out.raw[64 * i:64 * i + 64] for i in range(self.n)]
+
+    def abort(self):
+        if self._h:
+            lib().snaphash_batch_abort(self._h)
+            self._h = None
 
 
 # ---- host-only entry points (no device) ----------------------------------------------

@@ -18,12 +18,21 @@
 
 #include <algorithm>
 #include <atomic>
+#include <queue>
 #include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types only: the library is dlopen'ed when a ctx owns several devices
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+
 #include "hostpass.h"
+#include "hostsha.h"
 #include "sha512_core.h"
 #include "sha512_kernels.h"
 
@@ -56,8 +65,11 @@ double now_ms()
 
 } // namespace
 
-struct snaphash_ctx {
+// One engine: a device, its streams, staging buffers and kernel scratch.  A snaphash_ctx owns one
+// or several of these.
+struct DevCtx {
     int device = 0;
+    int index = 0; // position in snaphash_ctx::dev
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t copy_stream = nullptr; // H2D of batch k+1 overlaps the kernel of batch k
@@ -90,11 +102,55 @@ struct snaphash_ctx {
 };
 
 namespace {
+// single-process RCCL: ncclCommInitAll over the ctx's devices, one all-gather of
+// the padded digest slabs.  Resolved with dlopen so that a one-GPU caller never loads RCCL.
+struct Rccl {
+    void* lib = nullptr;
+    bool tried = false, ok = false;
+    std::string why;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::vector<ncclComm_t> comms;
+};
+} // namespace
 
-int fail(snaphash_ctx* c, int code, const std::string& msg)
+struct snaphash_batch;
+
+struct snaphash_ctx {
+    std::vector<std::unique_ptr<DevCtx>> dev;
+    uint32_t host_threads = 0;
+    uint32_t flags = 0;
+    Rccl rccl;
+    std::vector<uint8_t*> d_gather; // per device: n_devices * kmax * 64 bytes
+    size_t gather_cap = 0;          // rows (kmax) the gather buffers hold
+    snaphash_stats stats{};
+    snaphash_stats_ex ex{};
+    std::string last_error;
+    snaphash_batch* open_batch = nullptr;
+    DevCtx* d0() const { return dev[0].get(); }
+};
+
+namespace {
+
+int fail(DevCtx* c, int code, const std::string& msg)
 {
     if (c) c->last_error = msg;
     return code;
+}
+int fail(snaphash_ctx* x, int code, const std::string& msg)
+{
+    if (x) x->last_error = msg;
+    return code;
+}
+// error raised inside an engine -> the ctx's last_error
+int lift(snaphash_ctx* x, DevCtx* c, int rc)
+{
+    if (rc && x && c) x->last_error = c->last_error;
+    return rc;
 }
 #define HIP_TRY(c, expr)                                                                             \
     do {                                                                                             \
@@ -104,7 +160,7 @@ int fail(snaphash_ctx* c, int code, const std::string& msg)
                         std::string(#expr) + ": " + hipGetErrorString(e_));                          \
     } while (0)
 
-EventPair* next_events(snaphash_ctx* c, int kind)
+EventPair* next_events(DevCtx* c, int kind)
 {
     if (c->ev_used == c->ev_pool.size()) {
         EventPair p;
@@ -116,7 +172,7 @@ EventPair* next_events(snaphash_ctx* c, int kind)
     return p;
 }
 
-void collect_events(snaphash_ctx* c)
+void collect_events(DevCtx* c)
 {
     for (size_t i = 0; i < c->ev_used; ++i) {
         float ms = 0;
@@ -128,7 +184,7 @@ void collect_events(snaphash_ctx* c)
     c->ev_used = 0;
 }
 
-int ensure_state(snaphash_ctx* c, size_t n, bool want_digests)
+int ensure_state(DevCtx* c, size_t n, bool want_digests)
 {
     if (n > c->state_cap) {
         if (c->d_state) (void)hipFree(c->d_state);
@@ -145,7 +201,7 @@ int ensure_state(snaphash_ctx* c, size_t n, bool want_digests)
     return SNAPHASH_OK;
 }
 
-int ensure_jobs(snaphash_ctx* c, Job** h, Job** d, size_t* cap, size_t n)
+int ensure_jobs(DevCtx* c, Job** h, Job** d, size_t* cap, size_t n)
 {
     if (n <= *cap) return SNAPHASH_OK;
     size_t want = std::max<size_t>(n, 1024);
@@ -158,7 +214,7 @@ int ensure_jobs(snaphash_ctx* c, Job** h, Job** d, size_t* cap, size_t n)
     return SNAPHASH_OK;
 }
 
-int ensure_slots(snaphash_ctx* c)
+int ensure_slots(DevCtx* c)
 {
     for (Slot& s : c->slot) {
         if (!s.h_buf) HIP_TRY(c, hipHostMalloc((void**)&s.h_buf, c->staging, hipHostMallocDefault));
@@ -184,7 +240,7 @@ constexpr uint64_t kSplitMinBlocks = 32;
 
 uint64_t job_blocks(const Job& j) { return (j.nbytes >> 7) + 1; }
 
-hipError_t launch_kernel(uint32_t k, const Job* d_jobs, size_t n, snaphash_ctx* c, uint8_t* d_digests)
+hipError_t launch_kernel(uint32_t k, const Job* d_jobs, size_t n, DevCtx* c, uint8_t* d_digests)
 {
     if (k == SNAPHASH_KERNEL_PAIR) return launch_pair(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
     if (k == SNAPHASH_KERNEL_SPLIT) return launch_split(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
@@ -193,7 +249,7 @@ hipError_t launch_kernel(uint32_t k, const Job* d_jobs, size_t n, snaphash_ctx* 
 
 // h_jobs is sorted longest first.  Returns how many leading jobs go to the
 // few-long-streams kernel (*k_head) and which kernel takes the rest (*k_tail).
-size_t plan_kernels(const snaphash_ctx* c, const Job* h_jobs, size_t n, uint32_t* k_head, uint32_t* k_tail)
+size_t plan_kernels(const DevCtx* c, const Job* h_jobs, size_t n, uint32_t* k_head, uint32_t* k_tail)
 {
     *k_tail = SNAPHASH_KERNEL_WIDE;
     if (c->kernel_pref == SNAPHASH_KERNEL_WIDE || c->kernel_pref == SNAPHASH_KERNEL_SPLIT ||
@@ -223,7 +279,7 @@ size_t plan_kernels(const snaphash_ctx* c, const Job* h_jobs, size_t n, uint32_t
 // Sort (longest first, so the lanes of a wave finish together), upload and launch.
 // When `copied` is given, the job array goes up on the copy stream and the kernel waits
 // for that event (the staging engine); otherwise everything is on the launch stream.
-int launch_jobs(snaphash_ctx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_digests, hipEvent_t copied = nullptr)
+int launch_jobs(DevCtx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_digests, hipEvent_t copied = nullptr)
 {
     if (n == 0) return SNAPHASH_OK;
     std::stable_sort(h_jobs, h_jobs + n, [](const Job& a, const Job& b) { return a.nbytes > b.nbytes; });
@@ -249,7 +305,7 @@ int launch_jobs(snaphash_ctx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_
     return SNAPHASH_OK;
 }
 
-int sync_ctx(snaphash_ctx* c)
+int sync_ctx(DevCtx* c)
 {
     if (!c->pending && c->ev_used == 0) return SNAPHASH_OK;
     if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
@@ -260,7 +316,7 @@ int sync_ctx(snaphash_ctx* c)
     return SNAPHASH_OK;
 }
 
-void begin_call(snaphash_ctx* c)
+void begin_call(DevCtx* c)
 {
     c->stats = snaphash_stats{};
     c->t_call0 = now_ms();
@@ -273,9 +329,11 @@ struct Source {
     const char* path = nullptr;   // file source
     const uint8_t* mem = nullptr; // memory source
     uint64_t len = 0;
+    uint64_t gpu_len = 0;         // bytes this engine hashes: == len (whole stream, digest out) or a multiple of
+                                  // 128 below len (prefix only: the chaining value is handed to a host thread)
 };
 
-struct ReadOp { uint32_t src; uint64_t off; uint64_t n; uint8_t* dst; };
+struct ReadOp { uint32_t src; uint64_t off; uint64_t n; uint8_t* dst; bool to_eof; };
 
 void run_reads(const std::vector<Source>& src, const std::vector<ReadOp>& ops, std::atomic<int>& first_err,
                std::atomic<int64_t>& first_err_src)
@@ -300,6 +358,13 @@ void run_reads(const std::vector<Source>& src, const std::vector<ReadOp>& ops, s
                 else if (r == 0) err = EIO; // file shrank underneath us
                 else got += (uint64_t)r;
             }
+            if (!err && op.to_eof) { // io.Copy reads to EOF: a file that grew since its size was taken is an error too
+                uint8_t probe;
+                ssize_t r;
+                do r = pread(fd, &probe, 1, (off_t)(op.off + op.n)); while (r < 0 && errno == EINTR);
+                if (r > 0) err = EIO;
+                else if (r < 0) err = errno;
+            }
             if (fd >= 0) close(fd);
             if (err) {
                 int z = 0;
@@ -314,18 +379,28 @@ void run_reads(const std::vector<Source>& src, const std::vector<ReadOp>& ops, s
     for (auto& t : th) t.join();
 }
 
-int hash_sources(snaphash_ctx* c, const std::vector<Source>& src, uint8_t* digests, int32_t* status)
+// Hashes src[i].gpu_len bytes of every source on this engine's device.  digests (host, n*64, may be NULL):
+// receives the digests of whole streams; with NULL they stay in c->d_digests (row i = source i) for the
+// multi-device gather.  states (host, n*8 u64, may be NULL): receives the chaining values, needed for
+// prefix-only sources.  err_src: index of the failing source.
+int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, uint64_t* states, int* err_no,
+                 int64_t* err_src)
 {
     const size_t n = src.size();
+    if (err_no) *err_no = 0;
+    if (err_src) *err_src = -1;
     if (n == 0) return SNAPHASH_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
     int rc = ensure_slots(c);
     if (rc) return rc;
     rc = ensure_state(c, n, true);
     if (rc) return rc;
 
     std::vector<uint64_t> done(n, 0);
-    std::vector<uint32_t> active(n);
-    for (size_t i = 0; i < n; ++i) active[i] = (uint32_t)i;
+    std::vector<uint32_t> active;
+    active.reserve(n);
+    for (size_t i = 0; i < n; ++i)
+        if (src[i].gpu_len > 0 || src[i].len == 0) active.push_back((uint32_t)i); // a prefix of 0 bytes needs no launch
     std::atomic<int> first_err{0};
     std::atomic<int64_t> first_err_src{-1};
     std::vector<ReadOp> ops;
@@ -349,22 +424,24 @@ int hash_sources(snaphash_ctx* c, const std::vector<Source>& src, uint8_t* diges
         bool full = false;
         for (uint32_t id : active) {
             if (full) { still.push_back(id); continue; }
-            const uint64_t rem = src[id].len - done[id];
+            const uint64_t rem = src[id].gpu_len - done[id];
             const uint64_t take = rem <= quota ? rem : quota; // quota is a multiple of 128
             const uint64_t at = (used + kAlign - 1) & ~(uint64_t)(kAlign - 1);
             if (at + take > S) { full = true; still.push_back(id); continue; }
+            const bool last = take == rem;
+            const bool fin = last && src[id].gpu_len == src[id].len;
             Job j;
             j.data = (uint64_t)(uintptr_t)(sl.d_buf + at);
             j.nbytes = take;
             j.total_prev = done[id];
             j.idx = id;
-            j.flags = (done[id] == 0 ? kJobFirst : 0u) | (take == rem ? kJobFinal : 0u);
+            j.flags = (done[id] == 0 ? kJobFirst : 0u) | (fin ? kJobFinal : 0u);
             sl.h_jobs[nj++] = j;
-            if (take) ops.push_back(ReadOp{id, done[id], take, sl.h_buf + at});
+            if (take) ops.push_back(ReadOp{id, done[id], take, sl.h_buf + at, fin && src[id].path != nullptr});
             used = at + take;
             done[id] += take;
-            c->stats.blocks += padded_blocks(take, take == rem);
-            if (take != rem) still.push_back(id);
+            c->stats.blocks += padded_blocks(take, fin);
+            if (!last) still.push_back(id);
         }
         active.swap(still);
 
@@ -390,25 +467,332 @@ int hash_sources(snaphash_ctx* c, const std::vector<Source>& src, uint8_t* diges
     if (rc) return rc;
     if (first_err.load()) {
         const int64_t s = first_err_src.load();
-        if (status) {
-            for (size_t i = 0; i < n; ++i) status[i] = 0;
-            if (s >= 0) status[s] = first_err.load();
-        }
+        if (err_no) *err_no = first_err.load();
+        if (err_src) *err_src = s;
         return fail(c, SNAPHASH_EIO,
                     std::string(s >= 0 && src[s].path ? src[s].path : "<buffer>") + ": " + strerror(first_err.load()));
     }
-    HIP_TRY(c, hipMemcpy(digests, c->d_digests, n * 64, hipMemcpyDeviceToHost));
-    if (status) for (size_t i = 0; i < n; ++i) status[i] = 0;
-    for (size_t i = 0; i < n; ++i) c->stats.bytes_hashed += src[i].len;
+    if (digests) HIP_TRY(c, hipMemcpy(digests, c->d_digests, n * 64, hipMemcpyDeviceToHost));
+    if (states) HIP_TRY(c, hipMemcpy(states, c->d_state, n * 64, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) c->stats.bytes_hashed += src[i].gpu_len;
     c->stats.streams = n;
     return SNAPHASH_OK;
 }
 
-int hash_paths(snaphash_ctx* c, const char* const* paths, size_t n, uint8_t* digests, int32_t* status)
+// ---- RCCL gather of the digest vector (several devices) ---------------------------------
+
+bool rccl_load(snaphash_ctx* x)
+{
+    Rccl& r = x->rccl;
+    if (r.tried) return r.ok;
+    r.tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) { r.why = "librccl.so not found"; return false; }
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd) {
+        r.why = "librccl.so lacks a required symbol";
+        return false;
+    }
+    std::vector<int> devs;
+    for (auto& d : x->dev) devs.push_back(d->device);
+    std::vector<int> uniq = devs;
+    std::sort(uniq.begin(), uniq.end());
+    if (std::adjacent_find(uniq.begin(), uniq.end()) != uniq.end()) {
+        r.why = "a device ordinal repeats in the ctx (RCCL needs one rank per GPU)";
+        return false;
+    }
+    r.comms.assign(devs.size(), nullptr);
+    const ncclResult_t e = r.CommInitAll(r.comms.data(), (int)devs.size(), devs.data());
+    if (e != ncclSuccess) {
+        r.why = std::string("ncclCommInitAll: ") + (r.GetErrorString ? r.GetErrorString(e) : "error");
+        r.comms.clear();
+        return false;
+    }
+    r.ok = true;
+    return true;
+}
+
+// Every device d holds cnt[d] digests in dev[d]->d_digests (rows 0..cnt[d]-1).  Gathers them into `rows`
+// (host, ndev * kmax * 64): device d's rows start at d * kmax.
+int gather_digest_slabs(snaphash_ctx* x, const std::vector<size_t>& cnt, size_t kmax, std::vector<uint8_t>& rows)
+{
+    const size_t nd = x->dev.size();
+    rows.assign(nd * kmax * 64, 0);
+    const double t0 = now_ms();
+    bool use_rccl = !(x->flags & SNAPHASH_FLAG_NO_RCCL) && rccl_load(x);
+    if (use_rccl) {
+        if (kmax > x->gather_cap) {
+            for (size_t d = 0; d < x->d_gather.size(); ++d)
+                if (x->d_gather[d]) { (void)hipSetDevice(x->dev[d]->device); (void)hipFree(x->d_gather[d]); }
+            x->d_gather.assign(nd, nullptr);
+            x->gather_cap = 0;
+            for (size_t d = 0; d < nd; ++d) {
+                DevCtx* c = x->dev[d].get();
+                HIP_TRY(c, hipSetDevice(c->device));
+                if (hipMalloc((void**)&x->d_gather[d], nd * kmax * 64) != hipSuccess)
+                    return fail(x, SNAPHASH_ENOMEM, "hipMalloc of the gather buffer failed");
+            }
+            x->gather_cap = kmax;
+        }
+        for (size_t d = 0; d < nd; ++d) { // the slab every rank contributes is kmax rows: make sure it exists
+            DevCtx* c = x->dev[d].get();
+            HIP_TRY(c, hipSetDevice(c->device));
+            int rc = ensure_state(c, kmax, true);
+            if (rc) return lift(x, c, rc);
+        }
+        Rccl& r = x->rccl;
+        ncclResult_t e = r.GroupStart();
+        for (size_t d = 0; d < nd && e == ncclSuccess; ++d) {
+            DevCtx* c = x->dev[d].get();
+            (void)hipSetDevice(c->device);
+            e = r.AllGather(c->d_digests, x->d_gather[d], kmax * 64, ncclUint8, r.comms[d], c->stream);
+        }
+        const ncclResult_t e2 = r.GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        if (e != ncclSuccess)
+            return fail(x, SNAPHASH_EDEVICE, std::string("RCCL all-gather: ") + (r.GetErrorString ? r.GetErrorString(e) : "error"));
+        for (size_t d = 0; d < nd; ++d) {
+            DevCtx* c = x->dev[d].get();
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        DevCtx* c0 = x->d0();
+        HIP_TRY(c0, hipSetDevice(c0->device));
+        HIP_TRY(c0, hipMemcpy(rows.data(), x->d_gather[0], nd * kmax * 64, hipMemcpyDeviceToHost));
+        x->ex.gather_kind = 1;
+        if (x->flags & SNAPHASH_FLAG_CHECK_GATHER) { // the collective's parity check: per-device copies
+            std::vector<uint8_t> own(kmax * 64);
+            for (size_t d = 0; d < nd; ++d) {
+                DevCtx* c = x->dev[d].get();
+                HIP_TRY(c, hipSetDevice(c->device));
+                if (cnt[d]) HIP_TRY(c, hipMemcpy(own.data(), c->d_digests, cnt[d] * 64, hipMemcpyDeviceToHost));
+                if (memcmp(own.data(), rows.data() + d * kmax * 64, cnt[d] * 64) != 0)
+                    return fail(x, SNAPHASH_EDEVICE, "RCCL-gathered digest slab differs from the device's own copy");
+            }
+            x->ex.gather_checked = 1;
+        }
+    } else {
+        for (size_t d = 0; d < nd; ++d) {
+            DevCtx* c = x->dev[d].get();
+            HIP_TRY(c, hipSetDevice(c->device));
+            if (cnt[d]) HIP_TRY(c, hipMemcpy(rows.data() + d * kmax * 64, c->d_digests, cnt[d] * 64, hipMemcpyDeviceToHost));
+        }
+        x->ex.gather_kind = 2;
+    }
+    x->ex.gather_ms = now_ms() - t0;
+    return SNAPHASH_OK;
+}
+
+// ---- hybrid scheduling (opt-in): which streams finish on host threads ---------------------
+// Rates of the two engines for ONE stream (measured on MI355X, DESIGN.md sec. 4 / profiles): the GPU
+// advances a lone stream at kGpuStreamRate whatever surrounds it, a host core at kHostRate.
+constexpr double kGpuStreamRate = 38e6;
+constexpr double kHostRate = 0.45e9;
+constexpr double kGpuAggregate = 40e9; // PCIe-inclusive rate of one device's staging engine
+
+// Streams sorted longest first; moves the longest to the host pool while that shortens the modelled
+// makespan max(GPU, host).  Returns per-stream 1 = host.
+std::vector<uint8_t> plan_host_streams(const std::vector<Source>& src, unsigned threads, size_t ndev)
+{
+    const size_t n = src.size();
+    std::vector<uint8_t> on_host(n, 0);
+    if (!threads || n == 0) return on_host;
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return src[a].len > src[b].len; });
+    // prefix sums: G(k) = modelled GPU time with streams order[k..] on the GPU, H(k) = LPT makespan of
+    // order[0..k) on the host threads.  G falls and H rises with k: take the k that minimises max(G, H).
+    std::vector<double> suffix(n + 1, 0.0);
+    for (size_t k = n; k-- > 0;) suffix[k] = suffix[k + 1] + (double)src[order[k]].len;
+    auto gpu_time = [&](size_t k) {
+        if (k >= n) return 0.0;
+        return std::max((double)src[order[k]].len / kGpuStreamRate, suffix[k] / (kGpuAggregate * (double)ndev));
+    };
+    std::priority_queue<double, std::vector<double>, std::greater<double>> pool; // LPT over the host threads
+    for (unsigned t = 0; t < threads; ++t) pool.push(0.0);
+    double host_makespan = 0, best = gpu_time(0);
+    size_t best_k = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const double t = pool.top() + (double)src[order[k]].len / kHostRate;
+        pool.pop();
+        pool.push(t);
+        host_makespan = std::max(host_makespan, t);
+        const double m = std::max(gpu_time(k + 1), host_makespan);
+        if (m < best * 0.98) { best = m; best_k = k + 1; } // move only for a real gain
+        if (host_makespan > best) break;                   // H only grows from here
+    }
+    for (size_t k = 0; k < best_k; ++k) on_host[order[k]] = 1;
+    return on_host;
+}
+
+// ---- one call: hybrid split, LPT shards, per-device engines, gather ------------------------
+
+void merge_stats(snaphash_ctx* x)
+{
+    snaphash_stats t{};
+    for (auto& d : x->dev) {
+        const snaphash_stats& s = d->stats;
+        t.bytes_hashed += s.bytes_hashed;
+        t.blocks += s.blocks;
+        t.streams += s.streams;
+        t.launches += s.launches;
+        if (s.launches) t.kernel_used = s.kernel_used;
+        t.kernel_ms = std::max(t.kernel_ms, s.kernel_ms);
+        t.h2d_ms = std::max(t.h2d_ms, s.h2d_ms);
+    }
+    x->ex.gpu_bytes = t.bytes_hashed;
+    t.bytes_hashed += x->ex.host_bytes;
+    t.streams += x->ex.host_streams;
+    t.wall_ms = x->stats.wall_ms;
+    x->stats = t;
+}
+
+void begin_top(snaphash_ctx* x)
+{
+    x->stats = snaphash_stats{};
+    x->ex = snaphash_stats_ex{};
+    x->ex.struct_size = sizeof(snaphash_stats_ex);
+    x->ex.n_devices = (uint32_t)x->dev.size();
+    x->last_error.clear();
+    for (auto& d : x->dev) { begin_call(d.get()); d->t_call0 = 0; }
+}
+
+int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests, int32_t* status)
+{
+    const size_t n = src.size();
+    if (status) for (size_t i = 0; i < n; ++i) status[i] = 0;
+    if (n == 0) return SNAPHASH_OK;
+    const size_t nd = x->dev.size();
+    for (Source& s : src) s.gpu_len = s.len;
+    const std::vector<uint8_t> on_host = plan_host_streams(src, x->host_threads, nd);
+
+    // GPU part: LPT over the devices by SHA-512 block count (deterministic)
+    std::vector<uint32_t> gidx;
+    std::vector<uint32_t> hidx;
+    for (size_t i = 0; i < n; ++i) (on_host[i] ? hidx : gidx).push_back((uint32_t)i);
+    std::vector<std::vector<uint32_t>> member(nd);
+    if (nd == 1) {
+        member[0] = gidx;
+    } else {
+        std::vector<uint64_t> lens(gidx.size());
+        for (size_t k = 0; k < gidx.size(); ++k) lens[k] = src[gidx[k]].len;
+        std::vector<int32_t> shard(gidx.size());
+        if (!gidx.empty()) lpt_assign(lens.data(), lens.size(), (int)nd, shard.data());
+        for (size_t k = 0; k < gidx.size(); ++k) member[shard[k]].push_back(gidx[k]);
+    }
+
+    struct DevJob { std::vector<Source> sub; std::vector<uint8_t> dig; int rc = 0, err_no = 0; int64_t err_src = -1; };
+    std::vector<DevJob> job(nd);
+    const bool keep_on_device = nd > 1;
+    auto run_dev = [&](size_t d) {
+        DevJob& J = job[d];
+        J.sub.reserve(member[d].size());
+        for (uint32_t g : member[d]) J.sub.push_back(src[g]);
+        if (!keep_on_device) J.dig.resize(J.sub.size() * 64);
+        J.rc = hash_sources(x->dev[d].get(), J.sub, keep_on_device ? nullptr : J.dig.data(), nullptr, &J.err_no, &J.err_src);
+    };
+
+    // host part: a pool of threads over the host-assigned streams, longest first
+    std::atomic<size_t> hnext{0};
+    std::atomic<int> herr{0};
+    std::atomic<int64_t> herr_src{-1};
+    std::vector<double> hbusy(x->host_threads, 0.0);
+    std::stable_sort(hidx.begin(), hidx.end(), [&](uint32_t a, uint32_t b) { return src[a].len > src[b].len; });
+    auto run_host = [&](unsigned t) {
+        const double t0 = now_ms();
+        for (;;) {
+            const size_t k = hnext.fetch_add(1);
+            if (k >= hidx.size() || herr.load()) break;
+            const uint32_t g = hidx[k];
+            HostSha hs;
+            host_sha512_init(hs);
+            int err = 0;
+            if (src[g].mem) {
+                host_sha512_update(hs, src[g].mem, src[g].len);
+                host_sha512_final(hs, digests + 64 * (size_t)g);
+            } else {
+                err = host_sha512_file_from(hs, src[g].path, 0, src[g].len, digests + 64 * (size_t)g);
+            }
+            if (err) {
+                int z = 0;
+                if (herr.compare_exchange_strong(z, err)) herr_src.store(g);
+                break;
+            }
+        }
+        hbusy[t] = now_ms() - t0;
+    };
+
+    std::vector<std::thread> th;
+    const unsigned nh = hidx.empty() ? 0u : std::min<unsigned>(x->host_threads, (unsigned)hidx.size());
+    for (unsigned t = 0; t < nh; ++t) th.emplace_back(run_host, t);
+    if (nd == 1) {
+        run_dev(0);
+    } else {
+        std::vector<std::thread> dth;
+        for (size_t d = 0; d < nd; ++d) dth.emplace_back(run_dev, d);
+        for (auto& t : dth) t.join();
+    }
+    for (auto& t : th) t.join();
+
+    for (uint32_t g : hidx) { x->ex.host_bytes += src[g].len; }
+    x->ex.host_streams = hidx.size();
+    for (double b : hbusy) x->ex.host_ms = std::max(x->ex.host_ms, b);
+
+    // first error (lowest walk index) fails the call, as the reference's loop would (build.go:242-244)
+    int64_t bad = -1;
+    int bad_errno = 0, bad_rc = 0;
+    DevCtx* bad_dev = nullptr;
+    for (size_t d = 0; d < nd; ++d) {
+        if (!job[d].rc) continue;
+        const int64_t g = job[d].err_src >= 0 ? (int64_t)member[d][job[d].err_src] : (int64_t)n;
+        if (bad < 0 || g < bad) { bad = g; bad_errno = job[d].err_no; bad_rc = job[d].rc; bad_dev = x->dev[d].get(); }
+    }
+    if (herr.load() && (bad < 0 || herr_src.load() < bad)) {
+        bad = herr_src.load();
+        bad_errno = herr.load();
+        bad_rc = SNAPHASH_EIO;
+        bad_dev = nullptr;
+        x->last_error = std::string(src[bad].path ? src[bad].path : "<buffer>") + ": " + strerror(bad_errno);
+    }
+    if (bad_rc) {
+        if (bad_dev) x->last_error = bad_dev->last_error;
+        if (status && bad >= 0 && bad < (int64_t)n) status[bad] = bad_errno;
+        merge_stats(x);
+        return bad_rc;
+    }
+
+    if (nd == 1) {
+        for (size_t k = 0; k < member[0].size(); ++k) memcpy(digests + 64 * (size_t)member[0][k], job[0].dig.data() + 64 * k, 64);
+    } else {
+        std::vector<size_t> cnt(nd);
+        size_t kmax = 1;
+        for (size_t d = 0; d < nd; ++d) { cnt[d] = member[d].size(); kmax = std::max(kmax, cnt[d]); }
+        std::vector<uint8_t> rows;
+        int rc = gather_digest_slabs(x, cnt, kmax, rows);
+        if (rc) { merge_stats(x); return rc; }
+        for (size_t d = 0; d < nd; ++d)
+            for (size_t k = 0; k < cnt[d]; ++k) memcpy(digests + 64 * (size_t)member[d][k], rows.data() + (d * kmax + k) * 64, 64);
+    }
+    merge_stats(x);
+    return SNAPHASH_OK;
+}
+
+// sizes (may be NULL): the length each path is expected to have (the walk's lstat, build.go:240-252);
+// without it the length comes from stat() here.  Either way a file that is shorter or longer when it
+// is read fails the call (io.Copy reads to EOF: the record's size and digest must describe the same bytes).
+int hash_paths(snaphash_ctx* x, const char* const* paths, size_t n, const int64_t* sizes, uint8_t* digests, int32_t* status)
 {
     std::vector<Source> src(n);
     for (size_t i = 0; i < n; ++i) {
-        if (!paths[i]) return fail(c, SNAPHASH_EINVAL, "NULL path");
+        if (!paths[i]) return fail(x, SNAPHASH_EINVAL, "NULL path");
         struct stat st;
         int err = 0;
         // os.Open follows symlinks (helpers.go:189); a directory opens but its read fails with EISDIR
@@ -417,13 +801,15 @@ int hash_paths(snaphash_ctx* c, const char* const* paths, size_t n, uint8_t* dig
         else if (access(paths[i], R_OK) != 0) err = errno;
         if (err) {
             if (status) { for (size_t k = 0; k < n; ++k) status[k] = 0; status[i] = err; }
-            return fail(c, SNAPHASH_EIO, std::string(paths[i]) + ": " + strerror(err));
+            return fail(x, SNAPHASH_EIO, std::string(paths[i]) + ": " + strerror(err));
         }
         src[i].path = paths[i];
-        src[i].len = (uint64_t)st.st_size;
+        src[i].len = (uint64_t)((sizes && sizes[i] >= 0) ? sizes[i] : st.st_size);
     }
-    return hash_sources(c, src, digests, status);
+    return hash_sources_top(x, src, digests, status);
 }
+
+void end_top(snaphash_ctx* x, double t0) { x->stats.wall_ms = now_ms() - t0; }
 
 } // namespace
 
@@ -441,48 +827,10 @@ static int init_fail(int code, const std::string& what, hipError_t e = hipSucces
     return code;
 }
 
-int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
+static void destroy_dev(DevCtx* c)
 {
-    if (!out) return SNAPHASH_EINVAL;
-    *out = nullptr;
-    g_init_error.clear();
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) return init_fail(SNAPHASH_EDEVICE, "hipGetDeviceCount found no device", e);
-    int dev = -1;
-    if (cfg && cfg->struct_size >= sizeof(snaphash_config)) dev = cfg->device;
-    if (dev < 0 && (e = hipGetDevice(&dev)) != hipSuccess) return init_fail(SNAPHASH_EDEVICE, "hipGetDevice", e);
-    if (dev >= ndev) return init_fail(SNAPHASH_EINVAL, "device ordinal out of range");
-    hipDeviceProp_t prop;
-    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return init_fail(SNAPHASH_EDEVICE, "hipGetDeviceProperties", e);
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) // the code object is gfx950-only
-        return init_fail(SNAPHASH_EDEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-    if ((e = hipSetDevice(dev)) != hipSuccess) return init_fail(SNAPHASH_EDEVICE, "hipSetDevice", e);
-    snaphash_ctx* c = new (std::nothrow) snaphash_ctx();
-    if (!c) return SNAPHASH_ENOMEM;
-    c->device = dev;
-    if (cfg && cfg->struct_size >= sizeof(snaphash_config)) {
-        if (cfg->staging_bytes) c->staging = (cfg->staging_bytes + kAlign - 1) & ~(uint64_t)(kAlign - 1);
-        c->kernel_pref = cfg->kernel;
-        if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
-    }
-    if (c->staging < (1u << 16)) c->staging = 1u << 16;
-    if (!c->stream) {
-        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
-            delete c;
-            return init_fail(SNAPHASH_EDEVICE, "hipStreamCreateWithFlags", e);
-        }
-        c->own_stream = true;
-    }
-    *out = c;
-    return SNAPHASH_OK;
-}
-
-void snaphash_destroy(snaphash_ctx* c)
-{
-    if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (Slot& s : c->slot) {
         if (s.h_buf) (void)hipHostFree(s.h_buf);
         if (s.d_buf) (void)hipFree(s.d_buf);
@@ -500,58 +848,145 @@ void snaphash_destroy(snaphash_ctx* c)
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_digests) (void)hipFree(c->d_digests);
     for (EventPair& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
-int snaphash_sha512_files(snaphash_ctx* c, const char* const* paths, size_t n, uint8_t* digests, int32_t* status)
+int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
 {
-    if (!c || (n && (!paths || !digests))) return fail(c, SNAPHASH_EINVAL, "bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = sync_ctx(c);
-    if (rc) return rc;
-    begin_call(c);
-    rc = hash_paths(c, paths, n, digests, status);
-    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    if (!out) return SNAPHASH_EINVAL;
+    *out = nullptr;
+    g_init_error.clear();
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return init_fail(SNAPHASH_EDEVICE, "hipGetDeviceCount found no device", e);
+    const bool v1 = cfg && cfg->struct_size >= offsetof(snaphash_config, devices);
+    const bool v2 = cfg && cfg->struct_size >= sizeof(snaphash_config);
+    std::vector<int> devs;
+    if (v2 && cfg->n_devices > 0) {
+        if (!cfg->devices) return init_fail(SNAPHASH_EINVAL, "n_devices > 0 with a NULL device list");
+        if (cfg->n_devices == 1 && cfg->devices[0] == -1) {
+            for (int d = 0; d < ndev; ++d) devs.push_back(d); // every visible device
+        } else {
+            for (uint32_t k = 0; k < cfg->n_devices; ++k) devs.push_back(cfg->devices[k]);
+        }
+        if (cfg->stream && devs.size() > 1) return init_fail(SNAPHASH_EINVAL, "a caller stream needs a single-device ctx");
+    } else {
+        int dev = v1 ? cfg->device : -1;
+        if (dev < 0 && (e = hipGetDevice(&dev)) != hipSuccess) return init_fail(SNAPHASH_EDEVICE, "hipGetDevice", e);
+        devs.push_back(dev);
+    }
+    if (devs.size() > 64) return init_fail(SNAPHASH_EINVAL, "more than 64 engines");
+    std::unique_ptr<snaphash_ctx> x(new (std::nothrow) snaphash_ctx());
+    if (!x) return SNAPHASH_ENOMEM;
+    if (v2) { x->host_threads = std::min<uint32_t>(cfg->host_threads, 256); x->flags = cfg->flags; }
+    for (size_t k = 0; k < devs.size(); ++k) {
+        const int dev = devs[k];
+        if (dev < 0 || dev >= ndev) {
+            for (auto& d : x->dev) destroy_dev(d.get());
+            return init_fail(SNAPHASH_EINVAL, "device ordinal out of range");
+        }
+        hipDeviceProp_t prop;
+        int rc = SNAPHASH_OK;
+        std::string why;
+        if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) { rc = SNAPHASH_EDEVICE; why = "hipGetDeviceProperties"; }
+        else if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { // the code object is gfx950-only
+            rc = SNAPHASH_EDEVICE;
+            e = hipSuccess;
+            why = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        } else if ((e = hipSetDevice(dev)) != hipSuccess) { rc = SNAPHASH_EDEVICE; why = "hipSetDevice"; }
+        std::unique_ptr<DevCtx> c(rc ? nullptr : new (std::nothrow) DevCtx());
+        if (!rc && !c) rc = SNAPHASH_ENOMEM;
+        if (!rc) {
+            c->device = dev;
+            c->index = (int)k;
+            if (v1) {
+                if (cfg->staging_bytes) c->staging = (cfg->staging_bytes + kAlign - 1) & ~(uint64_t)(kAlign - 1);
+                c->kernel_pref = cfg->kernel;
+                if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
+            }
+            if (c->staging < (1u << 16)) c->staging = 1u << 16;
+            if (!c->stream) {
+                if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { rc = SNAPHASH_EDEVICE; why = "hipStreamCreateWithFlags"; }
+                else c->own_stream = true;
+            }
+        }
+        if (rc) {
+            for (auto& d : x->dev) destroy_dev(d.get());
+            return init_fail(rc, why, e);
+        }
+        x->dev.push_back(std::move(c));
+    }
+    *out = x.release();
+    return SNAPHASH_OK;
+}
+
+void snaphash_destroy(snaphash_ctx* x)
+{
+    if (!x) return;
+    if (x->open_batch) snaphash_batch_abort(x->open_batch);
+    for (size_t d = 0; d < x->d_gather.size(); ++d)
+        if (x->d_gather[d]) { (void)hipSetDevice(x->dev[d]->device); (void)hipFree(x->d_gather[d]); }
+    if (x->rccl.ok)
+        for (ncclComm_t c : x->rccl.comms) if (c) (void)x->rccl.CommDestroy(c);
+    for (auto& d : x->dev) destroy_dev(d.get());
+    delete x;
+}
+
+#define TOP_ENTER(x)                                                                  \
+    if ((x)->open_batch) return fail((x), SNAPHASH_EINVAL, "a streaming batch is open on this ctx"); \
+    for (auto& d_ : (x)->dev) {                                                       \
+        (void)hipSetDevice(d_->device);                                               \
+        int rc_ = sync_ctx(d_.get());                                                 \
+        if (rc_) return lift((x), d_.get(), rc_);                                     \
+    }                                                                                 \
+    begin_top(x);                                                                     \
+    const double t_top0_ = now_ms()
+
+int snaphash_sha512_files(snaphash_ctx* x, const char* const* paths, size_t n, uint8_t* digests, int32_t* status)
+{
+    if (!x || (n && (!paths || !digests))) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    TOP_ENTER(x);
+    int rc = hash_paths(x, paths, n, nullptr, digests, status);
+    end_top(x, t_top0_);
     return rc;
 }
 
-int snaphash_sha512_buffers(snaphash_ctx* c, const void* const* bufs, const uint64_t* lens, size_t n, uint8_t* digests)
+int snaphash_sha512_buffers(snaphash_ctx* x, const void* const* bufs, const uint64_t* lens, size_t n, uint8_t* digests)
 {
-    if (!c || (n && (!bufs || !lens || !digests))) return fail(c, SNAPHASH_EINVAL, "bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = sync_ctx(c);
-    if (rc) return rc;
-    begin_call(c);
+    if (!x || (n && (!bufs || !lens || !digests))) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    TOP_ENTER(x);
     std::vector<Source> src(n);
     for (size_t i = 0; i < n; ++i) {
-        if (!bufs[i] && lens[i]) return fail(c, SNAPHASH_EINVAL, "NULL buffer with non-zero length");
+        if (!bufs[i] && lens[i]) return fail(x, SNAPHASH_EINVAL, "NULL buffer with non-zero length");
         src[i].mem = bufs[i] ? (const uint8_t*)bufs[i] : (const uint8_t*)"";
         src[i].len = lens[i];
     }
-    rc = hash_sources(c, src, digests, nullptr);
-    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    int rc = hash_sources_top(x, src, digests, nullptr);
+    end_top(x, t_top0_);
     return rc;
 }
 
-int snaphash_sha512_device(snaphash_ctx* c, const void* d_base, const uint64_t* offsets, const uint64_t* lens,
+int snaphash_sha512_device(snaphash_ctx* x, const void* d_base, const uint64_t* offsets, const uint64_t* lens,
                            size_t n, void* d_digests)
 {
-    if (!c || (n && (!d_base || !offsets || !lens || !d_digests))) return fail(c, SNAPHASH_EINVAL, "bad argument");
-    if (((uintptr_t)d_base & 15) != 0) return fail(c, SNAPHASH_EINVAL, "d_base must be 16-byte aligned");
-    if (n > 0xffffffffull) return fail(c, SNAPHASH_EINVAL, "too many streams");
+    if (!x || (n && (!d_base || !offsets || !lens || !d_digests))) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    if (((uintptr_t)d_base & 15) != 0) return fail(x, SNAPHASH_EINVAL, "d_base must be 16-byte aligned");
+    if (n > 0xffffffffull) return fail(x, SNAPHASH_EINVAL, "too many streams");
+    if (x->open_batch) return fail(x, SNAPHASH_EINVAL, "a streaming batch is open on this ctx");
+    DevCtx* c = x->d0(); // resident data lives on one device: the ctx's first engine
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = sync_ctx(c); // one call in flight per ctx: the pinned job array is reused
-    if (rc) return rc;
+    if (rc) return lift(x, c, rc);
+    begin_top(x);
     begin_call(c);
     if (n == 0) return SNAPHASH_OK;
     rc = ensure_state(c, n, false);
-    if (rc) return rc;
+    if (rc) return lift(x, c, rc);
     rc = ensure_jobs(c, &c->h_jobs, &c->d_jobs, &c->jobs_cap, n);
-    if (rc) return rc;
+    if (rc) return lift(x, c, rc);
     for (size_t i = 0; i < n; ++i) {
-        if (offsets[i] & 15) return fail(c, SNAPHASH_EINVAL, "offsets must be 16-byte aligned");
-        if (lens[i] >> 35) return fail(c, SNAPHASH_EINVAL, "a resident stream is limited to 32 GiB per call (32-bit block counters)");
+        if (offsets[i] & 15) return fail(x, SNAPHASH_EINVAL, "offsets must be 16-byte aligned");
+        if (lens[i] >> 35) return fail(x, SNAPHASH_EINVAL, "a resident stream is limited to 32 GiB per call (32-bit block counters)");
         Job& j = c->h_jobs[i];
         j.data = (uint64_t)(uintptr_t)d_base + offsets[i];
         j.nbytes = lens[i];
@@ -562,82 +997,102 @@ int snaphash_sha512_device(snaphash_ctx* c, const void* d_base, const uint64_t* 
         c->stats.blocks += padded_blocks(lens[i], true);
     }
     c->stats.streams = n;
-    return launch_jobs(c, c->h_jobs, c->d_jobs, n, (uint8_t*)d_digests);
+    return lift(x, c, launch_jobs(c, c->h_jobs, c->d_jobs, n, (uint8_t*)d_digests));
 }
 
-int snaphash_sync(snaphash_ctx* c)
+int snaphash_sync(snaphash_ctx* x)
 {
-    if (!c) return SNAPHASH_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
-    return sync_ctx(c);
+    if (!x) return SNAPHASH_EINVAL;
+    for (auto& d : x->dev) {
+        HIP_TRY(d.get(), hipSetDevice(d->device));
+        int rc = sync_ctx(d.get());
+        if (rc) return lift(x, d.get(), rc);
+    }
+    const double wall = x->d0()->stats.wall_ms;
+    merge_stats(x);
+    if (x->stats.wall_ms == 0) x->stats.wall_ms = wall;
+    return SNAPHASH_OK;
 }
 
 // ---- the pass -----------------------------------------------------------------------
 
-static int tree_impl(snaphash_ctx* c, const char* build_dir, const char* data_tar, std::string& yaml)
+static int tree_impl(snaphash_ctx* x, const char* build_dir, const char* data_tar, const uint8_t* archive_digest,
+                     std::string& yaml)
 {
     // build.go:222 hashes the archive first; a missing archive fails before the walk
     struct stat st;
-    if (stat(data_tar, &st) != 0) return fail(c, SNAPHASH_EIO, std::string(data_tar) + ": " + strerror(errno));
+    if (data_tar && stat(data_tar, &st) != 0) return fail(x, SNAPHASH_EIO, std::string(data_tar) + ": " + strerror(errno));
     std::vector<Record> recs;
     int en = 0;
     int rc = walk_tree(build_dir, recs, &en);
-    if (rc) return fail(c, rc, rc == SNAPHASH_EIO ? std::string(build_dir) + ": " + strerror(en) : "Unknown file mode");
+    if (rc) return fail(x, rc, rc == SNAPHASH_EIO ? std::string(build_dir) + ": " + strerror(en) : "Unknown file mode");
     for (const Record& r : recs)
-        if (!plain_safe_name(r.name)) return fail(c, SNAPHASH_ENAME, "name needs YAML quoting: " + r.name);
+        if (!plain_safe_name(r.name)) return fail(x, SNAPHASH_ENAME, "name needs YAML quoting: " + r.name);
     std::vector<const char*> paths;
-    paths.push_back(data_tar); // element 0 = the archive, as in the Go batch shape
+    std::vector<int64_t> sizes;
+    if (data_tar) { paths.push_back(data_tar); sizes.push_back(-1); } // element 0 = the archive, as in the Go batch shape
     for (const Record& r : recs)
-        if (r.is_regular) paths.push_back(r.path.c_str());
-    std::vector<uint8_t> dig(paths.size() * 64);
-    rc = hash_paths(c, paths.data(), paths.size(), dig.data(), nullptr);
+        if (r.is_regular) { paths.push_back(r.path.c_str()); sizes.push_back(r.size); } // info.Size() of the walk's Lstat (build.go:240-252)
+    std::vector<uint8_t> dig(paths.size() * 64 + 64);
+    rc = hash_paths(x, paths.data(), paths.size(), sizes.data(), dig.data(), nullptr);
     if (rc) return rc;
-    // io.Copy reads to EOF, info.Size() comes from lstat: a file that grew or shrank
-    // between the two is an error here rather than a silently inconsistent record.
-    return emit_yaml(recs, dig.data(), dig.data() + 64, yaml);
+    const uint8_t* arch = data_tar ? dig.data() : archive_digest;
+    const uint8_t* files = data_tar ? dig.data() + 64 : dig.data();
+    return emit_yaml(recs, arch, files, yaml);
 }
 
-int snaphash_tree(snaphash_ctx* c, const char* build_dir, const char* data_tar, char** yaml_out, size_t* yaml_len)
+static int write_yaml_file(snaphash_ctx* x, const char* build_dir, const std::string& y)
 {
-    if (!c || !build_dir || !data_tar || !yaml_out) return fail(c, SNAPHASH_EINVAL, "bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = sync_ctx(c);
-    if (rc) return rc;
-    begin_call(c);
+    const std::string dir = std::string(build_dir) + "/DEBIAN";
+    const std::string path = dir + "/hashes.yaml";
+    int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644); // ioutil.WriteFile(..., 0644)
+    if (fd < 0) return fail(x, SNAPHASH_EIO, path + ": " + strerror(errno));
+    size_t off = 0;
+    while (off < y.size()) {
+        ssize_t w = write(fd, y.data() + off, y.size() - off);
+        if (w < 0) { if (errno == EINTR) continue; int e = errno; close(fd); return fail(x, SNAPHASH_EIO, path + ": " + strerror(e)); }
+        off += (size_t)w;
+    }
+    close(fd);
+    return SNAPHASH_OK;
+}
+
+int snaphash_tree_ex(snaphash_ctx* x, const char* build_dir, const char* data_tar, const uint8_t* archive_digest,
+                     int write_file, char** yaml_out, size_t* yaml_len)
+{
+    if (!x || !build_dir || (!data_tar && !archive_digest) || (!write_file && !yaml_out)) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    if (yaml_out) *yaml_out = nullptr;
+    if (write_file) {
+        const std::string dir = std::string(build_dir) + "/DEBIAN";
+        (void)mkdir(dir.c_str(), 0755); // os.MkdirAll(debianDir, 0755), error ignored (build.go:219)
+    }
+    TOP_ENTER(x);
     std::string y;
-    rc = tree_impl(c, build_dir, data_tar, y);
-    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    int rc = tree_impl(x, build_dir, data_tar, archive_digest, y);
+    if (!rc && write_file) rc = write_yaml_file(x, build_dir, y); // nothing is written on error (build.go:260-267)
+    end_top(x, t_top0_);
     if (rc) return rc;
-    char* p = (char*)malloc(y.size() + 1);
-    if (!p) return fail(c, SNAPHASH_ENOMEM, "malloc");
-    memcpy(p, y.data(), y.size());
-    p[y.size()] = 0;
-    *yaml_out = p;
+    if (yaml_out) {
+        char* p = (char*)malloc(y.size() + 1);
+        if (!p) return fail(x, SNAPHASH_ENOMEM, "malloc");
+        memcpy(p, y.data(), y.size());
+        p[y.size()] = 0;
+        *yaml_out = p;
+    }
     if (yaml_len) *yaml_len = y.size();
     return SNAPHASH_OK;
 }
 
-int snaphash_write_hashes(snaphash_ctx* c, const char* build_dir, const char* data_tar)
+int snaphash_tree(snaphash_ctx* x, const char* build_dir, const char* data_tar, char** yaml_out, size_t* yaml_len)
 {
-    if (!c || !build_dir || !data_tar) return fail(c, SNAPHASH_EINVAL, "bad argument");
-    std::string dir = std::string(build_dir) + "/DEBIAN";
-    (void)mkdir(dir.c_str(), 0755); // os.MkdirAll(debianDir, 0755), error ignored (build.go:219)
-    char* y = nullptr;
-    size_t n = 0;
-    int rc = snaphash_tree(c, build_dir, data_tar, &y, &n);
-    if (rc) return rc; // nothing is written on error (build.go:260-267)
-    const std::string path = dir + "/hashes.yaml";
-    int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644); // ioutil.WriteFile(..., 0644)
-    if (fd < 0) { free(y); return fail(c, SNAPHASH_EIO, path + ": " + strerror(errno)); }
-    size_t off = 0;
-    while (off < n) {
-        ssize_t w = write(fd, y + off, n - off);
-        if (w < 0) { if (errno == EINTR) continue; int e = errno; close(fd); free(y); return fail(c, SNAPHASH_EIO, path + ": " + strerror(e)); }
-        off += (size_t)w;
-    }
-    close(fd);
-    free(y);
-    return SNAPHASH_OK;
+    if (!x || !build_dir || !data_tar || !yaml_out) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    return snaphash_tree_ex(x, build_dir, data_tar, nullptr, 0, yaml_out, yaml_len);
+}
+
+int snaphash_write_hashes(snaphash_ctx* x, const char* build_dir, const char* data_tar)
+{
+    if (!x || !build_dir || !data_tar) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    return snaphash_tree_ex(x, build_dir, data_tar, nullptr, 1, nullptr, nullptr);
 }
 
 static int mismatch(snaphash_ctx* c, snaphash_mismatch* m, int kind, const std::string& name)
@@ -652,21 +1107,18 @@ static int mismatch(snaphash_ctx* c, snaphash_mismatch* m, int kind, const std::
     return fail(c, SNAPHASH_EMISMATCH, name + ": " + what[kind]);
 }
 
-int snaphash_verify(snaphash_ctx* c, const char* inst_dir, const char* data_tar, const char* yaml, size_t yaml_len,
+int snaphash_verify(snaphash_ctx* x, const char* inst_dir, const char* data_tar, const char* yaml, size_t yaml_len,
                     snaphash_mismatch* first)
 {
-    if (!c || !inst_dir || !yaml) return fail(c, SNAPHASH_EINVAL, "bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = sync_ctx(c);
-    if (rc) return rc;
-    begin_call(c);
+    if (!x || !inst_dir || !yaml) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    TOP_ENTER(x);
     ParsedHashes ph;
-    rc = parse_yaml(yaml, yaml_len, ph);
-    if (rc) return fail(c, rc, "hashes.yaml: parse error");
+    int rc = parse_yaml(yaml, yaml_len, ph);
+    if (rc) return fail(x, rc, "hashes.yaml: parse error");
     std::vector<Record> recs;
     int en = 0;
     rc = walk_tree(inst_dir, recs, &en);
-    if (rc) return fail(c, rc, rc == SNAPHASH_EIO ? std::string(inst_dir) + ": " + strerror(en) : "Unknown file mode");
+    if (rc) return fail(x, rc, rc == SNAPHASH_EIO ? std::string(inst_dir) + ": " + strerror(en) : "Unknown file mode");
 
     // Both lists are in walk order (per-directory byte-wise pre-order), so a
     // merge-style scan finds the first name present on one side only.
@@ -677,37 +1129,39 @@ int snaphash_verify(snaphash_ctx* c, const char* inst_dir, const char* data_tar,
         bool on_disk = false;
         for (size_t k = j; k < recs.size(); ++k)
             if (recs[k].name == ph.files[i].name) { on_disk = true; break; }
-        return on_disk ? mismatch(c, first, 2, recs[j].name) : mismatch(c, first, 1, ph.files[i].name);
+        return on_disk ? mismatch(x, first, 2, recs[j].name) : mismatch(x, first, 1, ph.files[i].name);
     }
-    if (i < ph.files.size()) return mismatch(c, first, 1, ph.files[i].name);
-    if (j < recs.size()) return mismatch(c, first, 2, recs[j].name);
+    if (i < ph.files.size()) return mismatch(x, first, 1, ph.files[i].name);
+    if (j < recs.size()) return mismatch(x, first, 2, recs[j].name);
 
     for (size_t k = 0; k < recs.size(); ++k) {
         const ParsedRecord& p = ph.files[k];
         const Record& r = recs[k];
         char a[11], b[11];
-        if (mode_string(p.st_mode, a) || mode_string(r.st_mode, b) || memcmp(a, b, 10) != 0) return mismatch(c, first, 5, r.name);
+        if (mode_string(p.st_mode, a) || mode_string(r.st_mode, b) || memcmp(a, b, 10) != 0) return mismatch(x, first, 5, r.name);
         if (r.is_regular) {
-            if (!p.has_size || p.size != r.size) return mismatch(c, first, 3, r.name);
+            if (!p.has_size || p.size != r.size) return mismatch(x, first, 3, r.name);
         } else if (p.has_size || !p.sha512_hex.empty()) {
-            return mismatch(c, first, 3, r.name);
+            return mismatch(x, first, 3, r.name);
         }
     }
+    // the caller handed over an archive to check: a yaml without a well-formed archive-sha512 cannot vouch for it
+    if (data_tar && (!ph.has_archive || ph.archive_hex.size() != 128)) return mismatch(x, first, 6, "archive-sha512");
     std::vector<const char*> paths;
+    std::vector<int64_t> sizes;
     std::vector<size_t> owner;
-    const bool check_archive = data_tar && ph.has_archive;
-    if (check_archive) { paths.push_back(data_tar); owner.push_back((size_t)-1); }
+    if (data_tar) { paths.push_back(data_tar); sizes.push_back(-1); owner.push_back((size_t)-1); }
     for (size_t k = 0; k < recs.size(); ++k)
-        if (recs[k].is_regular) { paths.push_back(recs[k].path.c_str()); owner.push_back(k); }
-    std::vector<uint8_t> dig(paths.size() * 64);
-    rc = hash_paths(c, paths.data(), paths.size(), dig.data(), nullptr);
-    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+        if (recs[k].is_regular) { paths.push_back(recs[k].path.c_str()); sizes.push_back(recs[k].size); owner.push_back(k); }
+    std::vector<uint8_t> dig(paths.size() * 64 + 64);
+    rc = hash_paths(x, paths.data(), paths.size(), sizes.data(), dig.data(), nullptr);
+    end_top(x, t_top0_);
     if (rc) return rc;
     for (size_t q = 0; q < paths.size(); ++q) {
         if (owner[q] == (size_t)-1) {
-            if (!digest_matches_hex(dig.data() + 64 * q, ph.archive_hex)) return mismatch(c, first, 6, "archive-sha512");
+            if (!digest_matches_hex(dig.data() + 64 * q, ph.archive_hex)) return mismatch(x, first, 6, "archive-sha512");
         } else if (!digest_matches_hex(dig.data() + 64 * q, ph.files[owner[q]].sha512_hex)) {
-            return mismatch(c, first, 4, recs[owner[q]].name);
+            return mismatch(x, first, 4, recs[owner[q]].name);
         }
     }
     return SNAPHASH_OK;
@@ -715,11 +1169,228 @@ int snaphash_verify(snaphash_ctx* c, const char* inst_dir, const char* data_tar,
 
 void snaphash_free(void* p) { free(p); }
 
+// ---- streaming batch (row f2): bytes are fed as another pass reads them -----------------------
+
+} // extern "C"
+
+struct snaphash_batch {
+    snaphash_ctx* x = nullptr;
+    DevCtx* c = nullptr;
+    size_t n = 0;
+    struct St {
+        uint64_t done = 0;    // bytes already placed into jobs (a multiple of 128 until the final segment)
+        int64_t job = -1;     // index of this stream's job in the slot being filled
+        uint32_t ntail = 0;
+        bool ended = false, finished = false;
+        uint8_t tail[128];
+    };
+    std::vector<St> st;
+    std::vector<uint32_t> in_slot; // streams that own a job in the slot being filled
+    unsigned batch = 0;           // slot index parity
+    uint64_t used = 0;            // bytes of the current slot in use
+    size_t nj = 0;                // jobs in the current slot
+    bool failed = false;
+    double t0 = 0;
+};
+
+namespace {
+
+Slot& cur_slot(snaphash_batch* b) { return b->c->slot[b->batch & 1]; }
+
+int batch_flush(snaphash_batch* b)
+{
+    DevCtx* c = b->c;
+    Slot& sl = cur_slot(b);
+    if (b->nj == 0) return SNAPHASH_OK;
+    if (b->used) {
+        EventPair* ev = next_events(c, 1);
+        if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
+        HIP_TRY(c, hipEventRecord(ev->a, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, b->used, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(ev->b, c->copy_stream));
+    }
+    int rc = launch_jobs(c, sl.h_jobs, sl.d_jobs, b->nj, c->d_digests, sl.copied);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(sl.done, c->stream));
+    sl.busy = true;
+    for (uint32_t s : b->in_slot) b->st[s].job = -1;
+    b->in_slot.clear();
+    ++b->batch;
+    b->used = 0;
+    b->nj = 0;
+    Slot& nx = cur_slot(b);
+    if (nx.busy) { HIP_TRY(c, hipEventSynchronize(nx.done)); nx.busy = false; }
+    return ensure_jobs(c, &nx.h_jobs, &nx.d_jobs, &nx.jobs_cap, std::max<size_t>(b->n, 1024));
+}
+
+// Places `n` bytes (p1[0..n1) then p2[0..n-n1)) of stream s into staging as (part of) a job.
+// n is a multiple of 128 unless final.  May flush.
+int batch_place(snaphash_batch* b, size_t s, const uint8_t* p1, size_t n1, const uint8_t* p2, size_t n2, bool final)
+{
+    DevCtx* c = b->c;
+    snaphash_batch::St& st = b->st[s];
+    const uint64_t S = c->staging;
+    size_t left1 = n1, left2 = n2;
+    for (;;) {
+        Slot& sl = cur_slot(b);
+        const size_t left = left1 + left2;
+        bool extend = false;
+        if (st.job >= 0) {
+            const Job& j = sl.h_jobs[st.job];
+            const uint64_t end = (j.data - (uint64_t)(uintptr_t)sl.d_buf) + j.nbytes;
+            if ((size_t)st.job == b->nj - 1 && end == b->used) extend = true; // contiguous with its own last bytes
+            else { int rc = batch_flush(b); if (rc) return rc; continue; }   // one segment per stream per launch
+        }
+        uint64_t at = extend ? b->used : ((b->used + kAlign - 1) & ~(uint64_t)(kAlign - 1));
+        uint64_t room = at < S ? S - at : 0;
+        uint64_t take = left;
+        if (take > room) take = room & ~(uint64_t)127;
+        if (take == 0 && left > 0) { // slot full
+            int rc = batch_flush(b);
+            if (rc) return rc;
+            continue;
+        }
+        if (!extend && b->nj >= cur_slot(b).jobs_cap) { int rc = batch_flush(b); if (rc) return rc; continue; }
+        const bool fin = final && take == left;
+        uint8_t* dst = sl.h_buf + at;
+        size_t t1 = std::min<size_t>(left1, take), t2 = (size_t)take - t1;
+        if (t1) memcpy(dst, p1 + (n1 - left1), t1);
+        if (t2) memcpy(dst + t1, p2 + (n2 - left2), t2);
+        left1 -= t1;
+        left2 -= t2;
+        if (extend) {
+            Job& j = sl.h_jobs[st.job];
+            j.nbytes += take;
+            if (fin) j.flags |= kJobFinal;
+        } else {
+            Job j;
+            j.data = (uint64_t)(uintptr_t)(sl.d_buf + at);
+            j.nbytes = take;
+            j.total_prev = st.done;
+            j.idx = (uint32_t)s;
+            j.flags = (st.done == 0 ? kJobFirst : 0u) | (fin ? kJobFinal : 0u);
+            st.job = (int64_t)b->nj;
+            sl.h_jobs[b->nj++] = j;
+            b->in_slot.push_back((uint32_t)s);
+        }
+        c->stats.blocks += (take >> 7) + (fin ? padded_blocks(take & 127, true) : 0);
+        b->used = at + take;
+        st.done += take;
+        c->stats.bytes_hashed += take;
+        if (left1 + left2 == 0) return SNAPHASH_OK;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int snaphash_batch_begin(snaphash_ctx* x, size_t n_streams, snaphash_batch** out)
+{
+    if (!x || !out) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    *out = nullptr;
+    if (x->dev.size() != 1) return fail(x, SNAPHASH_EINVAL, "streaming batches need a single-device ctx");
+    if (n_streams > 0xffffffffull) return fail(x, SNAPHASH_EINVAL, "too many streams");
+    TOP_ENTER(x);
+    DevCtx* c = x->d0();
+    int rc = ensure_slots(c);
+    if (!rc) rc = ensure_state(c, std::max<size_t>(n_streams, 1), true);
+    if (!rc) rc = ensure_jobs(c, &c->slot[0].h_jobs, &c->slot[0].d_jobs, &c->slot[0].jobs_cap, std::max<size_t>(n_streams, 1024));
+    if (rc) return lift(x, c, rc);
+    snaphash_batch* b = new (std::nothrow) snaphash_batch();
+    if (!b) return fail(x, SNAPHASH_ENOMEM, "new");
+    b->x = x;
+    b->c = c;
+    b->n = n_streams;
+    b->st.resize(n_streams);
+    b->t0 = t_top0_;
+    c->slot[0].busy = c->slot[1].busy = false;
+    x->open_batch = b;
+    *out = b;
+    return SNAPHASH_OK;
+}
+
+int snaphash_batch_append(snaphash_batch* b, size_t stream, const void* data, size_t n)
+{
+    if (!b) return SNAPHASH_EINVAL;
+    if (b->failed) return fail(b->x, SNAPHASH_EINVAL, "the batch has failed");
+    if (stream >= b->n || (!data && n) || b->st[stream].ended) return fail(b->x, SNAPHASH_EINVAL, "bad stream or buffer");
+    if (n == 0) return SNAPHASH_OK;
+    snaphash_batch::St& st = b->st[stream];
+    const uint8_t* p = (const uint8_t*)data;
+    if (st.ntail + n < 128) { // still less than a block: keep it on the host
+        memcpy(st.tail + st.ntail, p, n);
+        st.ntail += (uint32_t)n;
+        return SNAPHASH_OK;
+    }
+    const size_t whole = (st.ntail + n) & ~(size_t)127; // bytes that go to the GPU now
+    const size_t from_data = whole - st.ntail;
+    HIP_TRY(b->c, hipSetDevice(b->c->device));
+    int rc = batch_place(b, stream, st.tail, st.ntail, p, from_data, false);
+    if (rc) { b->failed = true; return lift(b->x, b->c, rc); }
+    st.ntail = (uint32_t)(n - from_data);
+    if (st.ntail) memcpy(st.tail, p + from_data, st.ntail);
+    return SNAPHASH_OK;
+}
+
+int snaphash_batch_end(snaphash_batch* b, size_t stream)
+{
+    if (!b) return SNAPHASH_EINVAL;
+    if (b->failed) return fail(b->x, SNAPHASH_EINVAL, "the batch has failed");
+    if (stream >= b->n) return fail(b->x, SNAPHASH_EINVAL, "bad stream");
+    snaphash_batch::St& st = b->st[stream];
+    if (st.ended) return SNAPHASH_OK;
+    st.ended = true;
+    HIP_TRY(b->c, hipSetDevice(b->c->device));
+    int rc = batch_place(b, stream, st.tail, st.ntail, nullptr, 0, true); // the final (< 128 byte, maybe empty) segment
+    if (rc) { b->failed = true; return lift(b->x, b->c, rc); }
+    st.ntail = 0;
+    return SNAPHASH_OK;
+}
+
+int snaphash_batch_finish(snaphash_batch* b, uint8_t* digests)
+{
+    if (!b) return SNAPHASH_EINVAL;
+    snaphash_ctx* x = b->x;
+    DevCtx* c = b->c;
+    int rc = (b->n && !digests) ? fail(x, SNAPHASH_EINVAL, "NULL digests") : SNAPHASH_OK;
+    if (!rc && b->failed) rc = fail(x, SNAPHASH_EINVAL, "the batch has failed");
+    (void)hipSetDevice(c->device);
+    for (size_t s = 0; s < b->n && !rc; ++s)
+        if (!b->st[s].ended) rc = snaphash_batch_end(b, s);
+    if (!rc) rc = lift(x, c, batch_flush(b));
+    if (!rc) rc = lift(x, c, sync_ctx(c));
+    c->slot[0].busy = c->slot[1].busy = false;
+    if (!rc && b->n && hipMemcpy(digests, c->d_digests, b->n * 64, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(x, SNAPHASH_EDEVICE, "D2H of the digests failed");
+    c->stats.streams = b->n;
+    merge_stats(x);
+    x->stats.wall_ms = now_ms() - b->t0;
+    x->open_batch = nullptr;
+    delete b;
+    return rc;
+}
+
+void snaphash_batch_abort(snaphash_batch* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->c->device);
+    (void)hipStreamSynchronize(b->c->copy_stream);
+    (void)hipStreamSynchronize(b->c->stream);
+    collect_events(b->c);
+    b->c->pending = false;
+    b->c->slot[0].busy = b->c->slot[1].busy = false;
+    b->x->open_batch = nullptr;
+    delete b;
+}
+
+} // extern "C"
+
 // ---- helpers.FilesAreEqual / DirUpdated (row f4) ----------------------------------------------
 
 namespace {
 
-int ensure_chunks(snaphash_ctx* c, size_t n)
+int ensure_chunks(DevCtx* c, size_t n)
 {
     if (n <= c->chunks_cap) return SNAPHASH_OK;
     const size_t want = std::max<size_t>(n, 4096);
@@ -733,7 +1404,7 @@ int ensure_chunks(snaphash_ctx* c, size_t n)
 }
 
 // Ranges (device addresses) -> chunk table -> kernel.  d_equal must hold one byte per pair.
-int launch_compare_ranges(snaphash_ctx* c, const std::vector<uint64_t>& a, const std::vector<uint64_t>& b,
+int launch_compare_ranges(DevCtx* c, const std::vector<uint64_t>& a, const std::vector<uint64_t>& b,
                           const std::vector<uint64_t>& lens, uint8_t* d_equal)
 {
     const size_t n = lens.size();
@@ -782,7 +1453,7 @@ bool read_exact(const char* path, uint64_t off, uint64_t n, uint8_t* dst)
     return got == n;
 }
 
-int files_equal_impl(snaphash_ctx* c, const char* const* a, const char* const* b, size_t n, uint8_t* equal)
+int files_equal_impl(DevCtx* c, const char* const* a, const char* const* b, size_t n, uint8_t* equal)
 {
     std::vector<CmpPair> todo;
     for (size_t i = 0; i < n; ++i) {
@@ -868,7 +1539,7 @@ int files_equal_impl(snaphash_ctx* c, const char* const* a, const char* const* b
         if (rc) return rc;
         for (size_t i = 0; i < segs.size(); ++i)
             if (!ok[i] || !res[i]) equal[todo[segs[i].t].idx] = 0;
-        first = (t < todo.size() && todo[t].done < todo[t].len) ? t : t; // t is the first pair with bytes left
+        first = t; // t is the first pair with bytes left
         while (first < todo.size() && todo[first].done >= todo[first].len) ++first;
     }
     return SNAPHASH_OK;
@@ -876,38 +1547,44 @@ int files_equal_impl(snaphash_ctx* c, const char* const* a, const char* const* b
 
 } // namespace
 
-int snaphash_files_equal(snaphash_ctx* c, const char* const* a, const char* const* b, size_t n, uint8_t* equal)
+
+extern "C" {
+
+int snaphash_files_equal(snaphash_ctx* x, const char* const* a, const char* const* b, size_t n, uint8_t* equal)
 {
-    if (!c || (n && (!a || !b || !equal))) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    if (!x || (n && (!a || !b || !equal))) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    TOP_ENTER(x);
+    DevCtx* c = x->d0(); // the comparison scan runs on the ctx's first engine
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = sync_ctx(c);
-    if (rc) return rc;
-    begin_call(c);
-    rc = files_equal_impl(c, a, b, n, equal);
-    if (c->t_call0 > 0) { c->stats.wall_ms = now_ms() - c->t_call0; c->t_call0 = 0; }
+    int rc = lift(x, c, files_equal_impl(c, a, b, n, equal));
+    merge_stats(x);
+    end_top(x, t_top0_);
     return rc;
 }
 
-int snaphash_ranges_equal_device(snaphash_ctx* c, const void* d_a, const uint64_t* off_a, const void* d_b,
+int snaphash_ranges_equal_device(snaphash_ctx* x, const void* d_a, const uint64_t* off_a, const void* d_b,
                                  const uint64_t* off_b, const uint64_t* lens, size_t n, void* d_equal)
 {
-    if (!c || (n && (!d_a || !d_b || !off_a || !off_b || !lens || !d_equal))) return fail(c, SNAPHASH_EINVAL, "bad argument");
-    if ((((uintptr_t)d_a) | ((uintptr_t)d_b)) & 15) return fail(c, SNAPHASH_EINVAL, "bases must be 16-byte aligned");
+    if (!x || (n && (!d_a || !d_b || !off_a || !off_b || !lens || !d_equal))) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    if ((((uintptr_t)d_a) | ((uintptr_t)d_b)) & 15) return fail(x, SNAPHASH_EINVAL, "bases must be 16-byte aligned");
+    if (x->open_batch) return fail(x, SNAPHASH_EINVAL, "a streaming batch is open on this ctx");
+    DevCtx* c = x->d0();
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = sync_ctx(c);
-    if (rc) return rc;
+    if (rc) return lift(x, c, rc);
+    begin_top(x);
     begin_call(c);
     if (n == 0) return SNAPHASH_OK;
     std::vector<uint64_t> va(n), vb(n), vl(n);
     for (size_t i = 0; i < n; ++i) {
-        if ((off_a[i] | off_b[i]) & 15) return fail(c, SNAPHASH_EINVAL, "offsets must be 16-byte aligned");
+        if ((off_a[i] | off_b[i]) & 15) return fail(x, SNAPHASH_EINVAL, "offsets must be 16-byte aligned");
         va[i] = (uint64_t)(uintptr_t)d_a + off_a[i];
         vb[i] = (uint64_t)(uintptr_t)d_b + off_b[i];
         vl[i] = lens[i];
         c->stats.bytes_hashed += lens[i];
     }
     c->stats.streams = n;
-    return launch_compare_ranges(c, va, vb, vl, (uint8_t*)d_equal);
+    return lift(x, c, launch_compare_ranges(c, va, vb, vl, (uint8_t*)d_equal));
 }
 
 int snaphash_dir_updated(snaphash_ctx* c, const char* dir_a, const char* dir_b, const char* pfx, char** names_out,
@@ -1009,6 +1686,9 @@ int snaphash_emit_yaml(const snaphash_records* r, const uint8_t archive_digest[6
                        char** yaml_out, size_t* yaml_len)
 {
     if (!r || !archive_digest || !yaml_out) return SNAPHASH_EINVAL;
+    if (!file_digests)
+        for (const Record& rec : r->v)
+            if (rec.is_regular) return SNAPHASH_EINVAL; // every regular record needs its digest
     std::string y;
     int rc = emit_yaml(r->v, archive_digest, file_digests, y);
     if (rc) return rc;
@@ -1025,17 +1705,18 @@ int snaphash_mode_string(uint32_t st_mode, char out[11]) { return out ? mode_str
 int snaphash_mode_parse(const char* s, uint32_t* st_mode) { return (s && st_mode) ? mode_parse(s, st_mode) : SNAPHASH_EINVAL; }
 int snaphash_lpt_assign(const uint64_t* lens, size_t n, int nshards, int32_t* shard_of) { return lpt_assign(lens, n, nshards, shard_of); }
 
-int snaphash_fill_synthetic_device(snaphash_ctx* c, void* d_base, const uint64_t* offsets, const uint64_t* lens,
+int snaphash_fill_synthetic_device(snaphash_ctx* x, void* d_base, const uint64_t* offsets, const uint64_t* lens,
                                    const uint64_t* file_index, size_t n)
 {
-    if (!c || (n && (!d_base || !offsets || !lens || !file_index))) return fail(c, SNAPHASH_EINVAL, "bad argument");
+    if (!x || (n && (!d_base || !offsets || !lens || !file_index))) return fail(x, SNAPHASH_EINVAL, "bad argument");
     if (n == 0) return SNAPHASH_OK;
+    DevCtx* c = x->d0();
     HIP_TRY(c, hipSetDevice(c->device));
     uint64_t* d = nullptr;
     HIP_TRY(c, hipMalloc((void**)&d, 3 * n * sizeof(uint64_t)));
     uint64_t maxlen = 0;
     for (size_t i = 0; i < n; ++i) {
-        if (offsets[i] & 7) { (void)hipFree(d); return fail(c, SNAPHASH_EINVAL, "offsets must be 8-byte aligned"); }
+        if (offsets[i] & 7) { (void)hipFree(d); return fail(x, SNAPHASH_EINVAL, "offsets must be 8-byte aligned"); }
         maxlen = std::max(maxlen, lens[i]);
     }
     hipError_t e = hipMemcpyAsync(d, offsets, n * 8, hipMemcpyHostToDevice, c->stream);
@@ -1044,7 +1725,7 @@ int snaphash_fill_synthetic_device(snaphash_ctx* c, void* d_base, const uint64_t
     if (e == hipSuccess) e = launch_fill_synthetic((uint8_t*)d_base, d, d + n, d + 2 * n, (uint32_t)n, maxlen, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail(c, SNAPHASH_EDEVICE, std::string("fill_synthetic: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(x, SNAPHASH_EDEVICE, std::string("fill_synthetic: ") + hipGetErrorString(e));
     return SNAPHASH_OK;
 }
 
@@ -1071,6 +1752,23 @@ const char* snaphash_last_error(const snaphash_ctx* c) { return c ? c->last_erro
 void snaphash_get_stats(const snaphash_ctx* c, snaphash_stats* out)
 {
     if (c && out) *out = c->stats;
+}
+
+int snaphash_get_stats_ex(const snaphash_ctx* c, snaphash_stats_ex* out)
+{
+    if (!c || !out || out->struct_size < sizeof(snaphash_stats_ex)) return SNAPHASH_EINVAL;
+    *out = c->ex;
+    out->struct_size = sizeof(snaphash_stats_ex);
+    out->n_devices = (uint32_t)c->dev.size();
+    return SNAPHASH_OK;
+}
+
+int snaphash_get_device_stats(const snaphash_ctx* c, uint32_t i, int32_t* device, snaphash_stats* out)
+{
+    if (!c || i >= c->dev.size()) return SNAPHASH_EINVAL;
+    if (device) *device = c->dev[i]->device;
+    if (out) *out = c->dev[i]->stats;
+    return SNAPHASH_OK;
 }
 
 } // extern "C"

@@ -49,3 +49,34 @@ extern "C" void core_sha512(const uint8_t* data, uint64_t len, uint64_t split, u
     for (int i = 0; i < 8; ++i)
         for (int b = 0; b < 8; ++b) out[8 * i + b] = (uint8_t)(H[i] >> (56 - 8 * b));
 }
+
+// ---- the library's host SHA-512 (hostsha.cpp: hybrid scheduling only) -----------------------
+#include "../snappy_amd/csrc/hostsha.cpp"
+
+// one-shot, optionally resumed at `split` (a multiple of 128) from the state after the prefix
+extern "C" void hostsha_buffer(const uint8_t* data, uint64_t n, uint64_t split, uint8_t* out)
+{
+    HostSha a;
+    host_sha512_init(a);
+    if (split && split <= n && (split & 127) == 0) {
+        host_sha512_update(a, data, split);
+        HostSha b;
+        host_sha512_resume(b, a.H, split); // what a hand-over from the GPU looks like
+        for (uint64_t off = split; off < n;) { // ragged update sizes
+            const uint64_t step = (off * 7 + 13) % 300 + 1;
+            const uint64_t k = step < n - off ? step : n - off;
+            host_sha512_update(b, data + off, k);
+            off += k;
+        }
+        host_sha512_final(b, out);
+        return;
+    }
+    host_sha512_update(a, data, n);
+    host_sha512_final(a, out);
+}
+extern "C" int hostsha_file(const char* path, uint64_t expect, uint8_t* out)
+{
+    HostSha a;
+    host_sha512_init(a);
+    return host_sha512_file_from(a, path, 0, expect, out);
+}

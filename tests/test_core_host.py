@@ -53,3 +53,29 @@ def test_round_constants_from_first_principles():
     assert got == K
     iv = text[text.index("IV512[8] = {"):]
     assert [int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ULL", iv[:iv.index("};")])] == IV
+
+
+def test_host_sha512_of_the_hybrid_scheduler(core, tmp_path_factory):
+    """snappy_amd/csrc/hostsha.cpp (the library's own host SHA-512, used only when host_threads > 0):
+    every tail length, resumed mid-stream from a chaining value, and the file reader's size check."""
+    import hashlib
+    so = str(tmp_path_factory.mktemp("core2") / "libcorehost2.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "tests", "core_host_harness.cpp")])
+    L = ctypes.CDLL(so)
+    L.hostsha_buffer.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p]
+    L.hostsha_file.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
+    rnd = os.urandom(3000)
+    out = ctypes.create_string_buffer(64)
+    for n in list(range(0, 300)) + [1000, 2047, 2048, 2049, 3000]:
+        for split in (0, 128, 256, 1024):
+            L.hostsha_buffer(rnd[:n], n, split, out)
+            assert out.raw == hashlib.sha512(rnd[:n]).digest(), (n, split)
+    p = tmp_path_factory.mktemp("f") / "blob"
+    blob = os.urandom((1 << 20) + 77)
+    p.write_bytes(blob)
+    assert L.hostsha_file(str(p).encode(), len(blob), out) == 0 and out.raw == hashlib.sha512(blob).digest()
+    import errno
+    assert L.hostsha_file(str(p).encode(), len(blob) - 1, out) == errno.EIO  # grew since its size was taken
+    assert L.hostsha_file(str(p).encode(), len(blob) + 1, out) == errno.EIO  # shrank
+    assert L.hostsha_file(b"/nonexistent/x", 0, out) == errno.ENOENT

@@ -40,6 +40,7 @@ def _worker(rank, world, port, sizes, q):
             data = torch.empty(max(total, 16), dtype=torch.uint8, device="cuda")
             ctx.fill_synthetic_device(data.data_ptr(), off, lens, np.ascontiguousarray(mine.astype(np.uint64)))
             slab = torch.zeros((plan.kmax, 64), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()  # the ctx stream is non-blocking: order it after torch's memset
             ctx.sha512_device(data.data_ptr(), off, lens, slab.data_ptr())
             ctx.sync()
             full = gather_digests(slab.cpu(), plan)

@@ -216,6 +216,7 @@ def test_config_c2_full_size_properties(ctx, oracle):
     dev = torch.empty(total, dtype=torch.uint8, device="cuda")
     ctx.fill_synthetic_device(dev.data_ptr(), off, lens, idx)
     out = torch.zeros((len(lens), 64), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the ctx stream is non-blocking: order it after torch's memset
     ctx.sha512_device(dev.data_ptr(), off, lens, out.data_ptr())
     ctx.sync()
     got = out.cpu().numpy()
@@ -226,10 +227,99 @@ def test_config_c2_full_size_properties(ctx, oracle):
     assert len({r.tobytes() for r in got}) == len(lens)
     perm = rng.permutation(len(lens))
     out2 = torch.zeros_like(out)
+    torch.cuda.synchronize()  # the ctx stream is non-blocking: order it after torch's memset
     ctx.sha512_device(dev.data_ptr(), off[perm].copy(), lens[perm].copy(), out2.data_ptr())
     ctx.sync()
     assert (out2.cpu().numpy() == got[perm]).all()
     assert hashlib.sha512(got.tobytes()).hexdigest() == hashlib.sha512(out2.cpu().numpy()[np.argsort(perm)].tobytes()).hexdigest()
+
+
+def test_config_c4_tree_sharded_eight_ways(built_lib, oracle):
+    """BASELINE config 4: the 10 000 x 1 MiB tree (+ archive) LPT-sharded 8 ways.  This box has one
+    GPU, so the eight shards are hashed one after the other, each through its own ctx (what each of
+    the eight ranks does), and gathered into walk order exactly as snappy_amd.sharded does.  The
+    full digest vector must equal the single-GPU config-2 vector; an oracle sample pins both."""
+    torch = _torch()
+    from snappy_amd import Context, synthetic
+    from snappy_amd.sharded import ShardPlan
+    lens = synthetic.config_sizes("C2")
+    n = len(lens)
+    idx = np.arange(n, dtype=np.uint64)
+    off, total = synthetic.pack_offsets(lens)
+    with Context() as c:
+        dev = torch.empty(total, dtype=torch.uint8, device="cuda")
+        c.fill_synthetic_device(dev.data_ptr(), off, lens, idx)
+        out = torch.zeros((n, 64), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        c.sha512_device(dev.data_ptr(), off, lens, out.data_ptr())
+        c.sync()
+        single = out.cpu().numpy()
+    plan = ShardPlan(lens, 8)
+    assert plan.counts.sum() == n and plan.counts.max() - plan.counts.min() <= 1  # equal files: LPT deals them evenly
+    gathered = np.zeros((8 * plan.kmax, 64), dtype=np.uint8)
+    for r in range(8):
+        mine = plan.members(r)
+        ml = np.ascontiguousarray(lens[mine])
+        mo = np.ascontiguousarray(off[mine])  # the shard's files where they already lie in HBM
+        with Context() as c:
+            slab = torch.zeros((plan.kmax, 64), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            c.sha512_device(dev.data_ptr(), mo, ml, slab.data_ptr())
+            c.sync()
+            assert c.stats()["streams"] == len(mine)
+            gathered[r * plan.kmax:(r + 1) * plan.kmax] = slab.cpu().numpy()
+    full = gathered[plan.row_of]
+    assert (full == single).all()
+    rng = np.random.default_rng(4)
+    for i in [0, n - 1] + list(rng.integers(0, n, size=14)):
+        assert full[i].tobytes() == oracle.sha512(oracle.fill_synthetic(int(lens[i]), int(i)).tobytes()), i
+
+
+def test_config_c5_full_size_properties(built_lib, oracle):
+    """BASELINE config 5 as defined: 100 000 Zipf-sized files, 1 KiB .. 256 MiB (uncapped head),
+    ~3.0 GiB.  The 256 MiB head file is a single stream of 2.1 M sequential blocks (seconds on
+    the GPU), so this is the slowest test of the suite.  Checks: an oracle sample that includes the
+    head file and the smallest file; all digests distinct; the 8-way LPT shards (config 5 runs on
+    8 GPUs) reproduce the same vector shard by shard."""
+    torch = _torch()
+    from snappy_amd import Context, synthetic
+    from snappy_amd.sharded import ShardPlan
+    lens = synthetic.config_sizes("C5")
+    n = len(lens)
+    assert n == 100000 and int(lens.max()) == 1 << 28 and int(lens.min()) == 1024
+    off, total = synthetic.pack_offsets(lens)
+    idx = np.arange(n, dtype=np.uint64)
+    with Context() as c:
+        dev = torch.empty(total, dtype=torch.uint8, device="cuda")
+        c.fill_synthetic_device(dev.data_ptr(), off, lens, idx)
+        out = torch.zeros((n, 64), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        c.sha512_device(dev.data_ptr(), off, lens, out.data_ptr())
+        c.sync()
+        got = out.cpu().numpy()
+        head = int(np.argmax(lens))
+        rng = np.random.default_rng(5)
+        order = np.argsort(lens)
+        sample = [head, int(order[0]), int(order[-2]), int(order[-3])] + [int(x) for x in rng.integers(0, n, size=60)]
+        for i in sample:
+            o, ln = int(off[i]), int(lens[i])
+            assert got[i].tobytes() == oracle.sha512(dev[o:o + ln].cpu().numpy().tobytes()), i
+        assert len({r.tobytes() for r in got}) == n
+        # config 5 is quoted on 8 GPUs with load-balanced shards: the LPT plan's makespan is the head file
+        plan = ShardPlan(lens, 8)
+        blocks = lens // np.uint64(128) + np.uint64(1)
+        loads = np.array([int(blocks[plan.members(r)].sum()) for r in range(8)])
+        assert loads.max() >= int(blocks.max()) and loads.max() - loads.min() <= 1000  # balanced to 0.03 %
+        for r in (0, 7):  # two of the eight shards through the kernels again (the head's shard is one of them or not: both orders occur)
+            mine = plan.members(r)
+            ml, mo = np.ascontiguousarray(lens[mine]), np.ascontiguousarray(off[mine])
+            if int(ml.max()) > (64 << 20):
+                continue  # the head's shard would cost another 7 s; its digest is already pinned above
+            slab = torch.zeros((len(mine), 64), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            c.sha512_device(dev.data_ptr(), mo, ml, slab.data_ptr())
+            c.sync()
+            assert (slab.cpu().numpy() == got[mine]).all()
 
 
 def test_config_c5_zipf_scaled_vs_oracle(built_lib, oracle):
@@ -245,6 +335,7 @@ def test_config_c5_zipf_scaled_vs_oracle(built_lib, oracle):
         dev = torch.empty(total, dtype=torch.uint8, device="cuda")
         c.fill_synthetic_device(dev.data_ptr(), off, lens, idx)
         out = torch.zeros((len(lens), 64), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the ctx stream is non-blocking: order it after torch's memset
         c.sha512_device(dev.data_ptr(), off, lens, out.data_ptr())
         c.sync()
         st = c.stats()
@@ -320,6 +411,7 @@ def test_device_entry_point_argument_checks(built_lib):
     from snappy_amd import Context, SnaphashError, _lib
     buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
     out = torch.zeros((2, 64), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the ctx stream is non-blocking: order it after torch's memset
     with Context() as c:
         for off, ln in (([8, 0], [16, 16]), ([0, 16], [1 << 35, 16])):  # misaligned offset; oversize stream
             with pytest.raises(SnaphashError) as e:
@@ -376,12 +468,14 @@ def test_config_c3_full_size_properties(built_lib, oracle):
         dev = torch.empty(total, dtype=torch.uint8, device="cuda")
         c.fill_synthetic_device(dev.data_ptr(), off, lens, idx)
         out = torch.zeros((len(lens), 64), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the ctx stream is non-blocking: order it after torch's memset
         c.sha512_device(dev.data_ptr(), off, lens, out.data_ptr())
         c.sync()
         st = c.stats()
         got = out.cpu().numpy()
         perm = np.random.default_rng(4).permutation(len(lens))
         out2 = torch.zeros_like(out)
+        torch.cuda.synchronize()  # the ctx stream is non-blocking: order it after torch's memset
         c.sha512_device(dev.data_ptr(), off[perm].copy(), lens[perm].copy(), out2.data_ptr())
         c.sync()
         got2 = out2.cpu().numpy()

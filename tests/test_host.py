@@ -20,12 +20,14 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert declared == set(_lib.EXPORTS)
     for s in declared:
         assert hasattr(built_lib, s), s
-    assert built_lib.snaphash_abi_version() == 1
+    assert built_lib.snaphash_abi_version() == 2
 
 
 def test_struct_layouts_match_header(built_lib):
     from snappy_amd import _lib
-    assert ctypes.sizeof(_lib.Config) == 32
+    assert ctypes.sizeof(_lib.Config) == 56
+    assert _lib.Config.devices.offset == 32  # an ABI-1 caller passes struct_size 32: the prefix is unchanged
+    assert ctypes.sizeof(_lib.StatsEx) == 64
     assert ctypes.sizeof(_lib.Stats) == 56
     assert ctypes.sizeof(_lib.Mismatch) == 8 + 4096
     assert ctypes.sizeof(_lib.Record) == 32

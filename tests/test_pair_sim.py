@@ -96,10 +96,10 @@ def test_generated_inc_is_current():
         n = gp.write_inc(fresh)
         assert open(fresh).read() == open(path).read()
     if gp.LOOP_ROUNDS:
-        L = gp.LOOP_ROUNDS  # body: L rounds of 23 VALU, L/2 (ds_read2_b64 + s_waitcnt); + loop control
-        assert n == 2 + 2 + L * 23 + L + 1 + 3 + 1
+        L = gp.LOOP_ROUNDS  # body: L rounds of 19 VALU, L/2 (ds_read2_b64 + s_waitcnt); + loop control
+        assert n == 2 + 2 + L * 19 + L + 1 + 3 + 1
     else:
-        assert n == 2 + 80 * 23 + 39 + 40  # per round 23 VALU; per two rounds one ds_read2_b64 and one s_waitcnt
+        assert n == 2 + 80 * 19 + 39 + 40  # per round 19 VALU; per two rounds one ds_read2_b64 and one s_waitcnt
 
 
 def test_dpp_hazard_distance():

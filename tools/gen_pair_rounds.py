@@ -8,7 +8,9 @@ holding its chaining value.  Splitting a stream over two
 lanes of the same wave -- lane A owns (e,f,g,h) and computes T1, lane B owns
 (a,b,c,d) and computes T2 -- lets ONE instruction serve Sigma1(e) in the A lanes
 and Sigma0(a) in the B lanes (per-lane rotate amounts in a VGPR), and likewise
-Ch/Maj and the adds: 24 instructions per round instead of 32.
+Ch/Maj and the adds.  With CDNA4's v_bitop3_b32 (three-input truth-table op) the three-way
+xor of the Sigma functions and M = x0 ^ (x2 & role) are one instruction per half:
+19 instructions per round (33 - 6 on a single lane with the same op).
 
 Lane layout (64 lanes = 32 streams): in every group of 8 lanes, lanes 0-3 are
 role A of four streams and lanes 4-7 role B of the same streams mirrored, so
@@ -61,19 +63,19 @@ def one_round(e, i, kw_prefetch, wait):
     if kw_prefetch is not None:
         e(("ds_read2_b64", "KW%d" % ((i + 2) & 3), "ADDR", kw_prefetch))
     if ORDER.startswith("seed:"):
-        # experiment: a random topological order of the round's 19 non-DPP instructions (the four
+        # experiment: a random topological order of the round's 15 non-DPP instructions (the four
         # DPP adds stay last, in order); dependencies are read off the operand names
         import random
         body = [("alignbit", "Tl", x[0] + "h", x[0] + "l", "C1"), ("alignbit", "Th", x[0] + "l", x[0] + "h", "C1"),
                 ("alignbit", "Ul", x[0] + "h", x[0] + "l", "C2"), ("alignbit", "Uh", x[0] + "l", x[0] + "h", "C2"),
-                ("xor", "Tl", "Tl", "Ul"), ("xor", "Th", "Th", "Uh"), ("xor", "Tl", "Tl", x[0] + "l"),
-                ("xor", "Th", "Th", x[0] + "h"), ("alignbit", "Sl", "Th", "Tl", "C3"), ("alignbit", "Sh", "Tl", "Th", "C3"),
-                ("and", "Ml", x[2] + "l", "MB"), ("and", "Mh", x[2] + "h", "MB"), ("xor", "Ml", "Ml", x[0] + "l"),
-                ("xor", "Mh", "Mh", x[0] + "h"), ("bfi", "BFl", "Ml", x[1] + "l", x[2] + "l"),
+                ("bitop3", "Tl", "Tl", "Ul", x[0] + "l", 0x96), ("bitop3", "Th", "Th", "Uh", x[0] + "h", 0x96),
+                ("alignbit", "Sl", "Th", "Tl", "C3"), ("alignbit", "Sh", "Tl", "Th", "C3"),
+                ("bitop3", "Ml", x[0] + "l", x[2] + "l", "MB", 0x78), ("bitop3", "Mh", x[0] + "h", x[2] + "h", "MB", 0x78),
+                ("bfi", "BFl", "Ml", x[1] + "l", x[2] + "l"),
                 ("bfi", "BFh", "Mh", x[1] + "h", x[2] + "h"), ("add64", "VV", "S", "BF"), ("add64", "TT", x[3], kw),
                 ("add64", "V2", "VV", "TT")]
         def regs_of(t, write):
-            names = [t[1]] if write else list(t[2:])
+            names = [t[1]] if write else [q for q in t[2:] if isinstance(q, str)]
             out = set()
             for nme in names:
                 out |= {nme + "l", nme + "h"} if t[0] == "add64" else {nme}
@@ -109,22 +111,18 @@ def one_round(e, i, kw_prefetch, wait):
         return
     if ORDER == "interleave":
         e(("alignbit", "Tl", x[0] + "h", x[0] + "l", "C1"))
-        e(("and", "Ml", x[2] + "l", "MB"))
         e(("alignbit", "Th", x[0] + "l", x[0] + "h", "C1"))
-        e(("and", "Mh", x[2] + "h", "MB"))
         e(("alignbit", "Ul", x[0] + "h", x[0] + "l", "C2"))
-        e(("xor", "Ml", "Ml", x[0] + "l"))
         e(("alignbit", "Uh", x[0] + "l", x[0] + "h", "C2"))
-        e(("xor", "Mh", "Mh", x[0] + "h"))
+        e(("bitop3", "Ml", x[0] + "l", x[2] + "l", "MB", 0x78))
+        e(("bitop3", "Mh", x[0] + "h", x[2] + "h", "MB", 0x78))
+        e(("bitop3", "Tl", "Tl", "Ul", x[0] + "l", 0x96))
+        e(("bitop3", "Th", "Th", "Uh", x[0] + "h", 0x96))
         e(("bfi", "BFl", "Ml", x[1] + "l", x[2] + "l"))
-        e(("xor", "Tl", "Tl", "Ul"))
         e(("bfi", "BFh", "Mh", x[1] + "h", x[2] + "h"))
-        e(("xor", "Th", "Th", "Uh"))
         if wait is not None:
             e(("waitcnt", wait))
         e(("add64", "TT", x[3], kw))
-        e(("xor", "Tl", "Tl", x[0] + "l"))
-        e(("xor", "Th", "Th", x[0] + "h"))
         e(("alignbit", "Sl", "Th", "Tl", "C3"))
         e(("alignbit", "Sh", "Tl", "Th", "C3"))
         e(("add64", "VV", "S", "BF"))
@@ -139,17 +137,13 @@ def one_round(e, i, kw_prefetch, wait):
     e(("alignbit", "Th", x[0] + "l", x[0] + "h", "C1"))
     e(("alignbit", "Ul", x[0] + "h", x[0] + "l", "C2"))
     e(("alignbit", "Uh", x[0] + "l", x[0] + "h", "C2"))
-    e(("xor", "Tl", "Tl", "Ul"))
-    e(("xor", "Th", "Th", "Uh"))
-    e(("xor", "Tl", "Tl", x[0] + "l"))
-    e(("xor", "Th", "Th", x[0] + "h"))
+    e(("bitop3", "Tl", "Tl", "Ul", x[0] + "l", 0x96))   # three-way xor
+    e(("bitop3", "Th", "Th", "Uh", x[0] + "h", 0x96))
     e(("alignbit", "Sl", "Th", "Tl", "C3"))
     e(("alignbit", "Sh", "Tl", "Th", "C3"))
     # M = x0 ^ (x2 & MB)   [A: e ; B: a ^ c];  BF = bfi(M, x1, x2)   [A: Ch(e,f,g) ; B: Maj(a,b,c)]
-    e(("and", "Ml", x[2] + "l", "MB"))
-    e(("and", "Mh", x[2] + "h", "MB"))
-    e(("xor", "Ml", "Ml", x[0] + "l"))
-    e(("xor", "Mh", "Mh", x[0] + "h"))
+    e(("bitop3", "Ml", x[0] + "l", x[2] + "l", "MB", 0x78))
+    e(("bitop3", "Mh", x[0] + "h", x[2] + "h", "MB", 0x78))
     e(("bfi", "BFl", "Ml", x[1] + "l", x[2] + "l"))
     e(("bfi", "BFh", "Mh", x[1] + "h", x[2] + "h"))
     e(("add64", "VV", "S", "BF"))            # A: Sigma1+Ch ; B: T2 = Sigma0+Maj
@@ -215,6 +209,8 @@ def to_asm(ins):
             out.append("v_and_b32 %s, %s, %s" % (v(t[1]), v(t[2]), v(t[3])))
         elif op == "bfi":
             out.append("v_bfi_b32 %s, %s, %s, %s" % (v(t[1]), v(t[2]), v(t[3]), v(t[4])))
+        elif op == "bitop3":  # t[5] = truth table f(0xF0, 0xCC, 0xAA) over (src0, src1, src2)
+            out.append("v_bitop3_b32 %s, %s, %s, %s bitop3:0x%x" % (v(t[1]), v(t[2]), v(t[3]), v(t[4]), t[5]))
         elif op == "add64":
             out.append("v_lshl_add_u64 %s, %s, 0, %s" % (vp(t[1]), vp(t[2]), vp(t[3])))
         elif op == "add_co_dpp":
@@ -331,6 +327,13 @@ def simulate(ins, regs, lds):
         elif op == "bfi":
             m = g(t[2])
             regs[t[1]] = (m & g(t[3])) | (~m & g(t[4]))
+        elif op == "bitop3":
+            a_, b_, c_ = g(t[2]), g(t[3]), g(t[4])
+            r = np.zeros(64, dtype=np.uint32)
+            for m in range(8):
+                if t[5] & (1 << m):
+                    r |= (a_ if m & 4 else ~a_) & (b_ if m & 2 else ~b_) & (c_ if m & 1 else ~c_)
+            regs[t[1]] = r
         elif op == "add64":
             with np.errstate(over="ignore"):
                 r = g64(t[2]) + g64(t[3])

@@ -23,6 +23,7 @@ for name, k in (("pair", _lib.KERNEL_PAIR), ("split", _lib.KERNEL_SPLIT), ("wide
         if ref is None:
             c.fill_synthetic_device(dev.data_ptr(), off, lens, np.arange(len(lens), dtype=np.uint64))
         out = torch.zeros((len(lens), 64), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the ctx stream is non-blocking: order it after torch's memset
         n = iters if name == "pair" else max(20, iters // 6)
         bad = 0
         for it in range(n):

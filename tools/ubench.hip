@@ -170,6 +170,117 @@ __global__ __launch_bounds__(1024) void k_lds_barrier_pingpong(uint64_t* cycles,
     if (v == 0x12345678) sink[0] = v;
 }
 
+
+// ---- round 2 additions -------------------------------------------------------------------
+// CDNA4's three-input truth-table op (xor3, Ch, Maj in one instruction)
+#define BITOP3_I(n) "v_bitop3_b32 %" #n ", %" #n ", %16, %17 bitop3:0x96\n"
+#define BITOP3_D(n) "v_bitop3_b32 %0, %0, %16, %17 bitop3:0x96\n"
+DEFINE_KERNEL(k_bitop3, , BITOP3_I, BITOP3_D)
+
+// the SAME operation in the 4-byte (VOP2) and the 8-byte (VOP3) encoding: is the half rate of
+// alignbit/bfi/perm/lshl_add a property of the encoding width or of the operation?
+#define XOR64_I(n) "v_xor_b32_e64 %" #n ", %" #n ", %17\n"
+#define XOR64_D(n) "v_xor_b32_e64 %0, %0, %17\n"
+DEFINE_KERNEL(k_xor_e64, , XOR64_I, XOR64_D)
+
+#define ADDU32_I(n) "v_add_u32_e32 %" #n ", %" #n ", %17\n"
+#define ADDU32_D(n) "v_add_u32_e32 %0, %0, %17\n"
+DEFINE_KERNEL(k_add_u32_e32, , ADDU32_I, ADDU32_D)
+
+#define ADDU64E_I(n) "v_add_u32_e64 %" #n ", %" #n ", %17\n"
+#define ADDU64E_D(n) "v_add_u32_e64 %0, %0, %17\n"
+DEFINE_KERNEL(k_add_u32_e64, , ADDU64E_I, ADDU64E_D)
+
+#define FMA_I(n) "v_fma_f32 %" #n ", %" #n ", %16, %17\n"
+#define FMA_D(n) "v_fma_f32 %0, %0, %16, %17\n"
+DEFINE_KERNEL(k_fma_f32, , FMA_I, FMA_D)
+
+#define ADD3_I(n) "v_add3_u32 %" #n ", %" #n ", %16, %17\n"
+#define ADD3_D(n) "v_add3_u32 %0, %0, %16, %17\n"
+DEFINE_KERNEL(k_add3_u32, , ADD3_I, ADD3_D)
+
+#define MOV_I(n) "v_mov_b32_e32 %" #n ", %17\n"
+#define MOV_D(n) "v_mov_b32_e32 %0, %0\n"
+DEFINE_KERNEL(k_mov_e32, , MOV_I, MOV_D)
+
+#define ROR8_I(n) "v_mov_b32_dpp %" #n ", %17 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+#define ROR8_D(n) "v_mov_b32_dpp %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+DEFINE_KERNEL(k_dpp_row_ror8, , ROR8_I, ROR8_D)
+
+#define SHR8_I(n) "v_add_u32_dpp %" #n ", %17, %" #n " row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+#define SHR8_D(n) "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+DEFINE_KERNEL(k_dppadd_row_shr8, , SHR8_I, SHR8_D)
+
+#define MAD64I(n, m) "v_mad_u64_u32 %" #m ", vcc, %" #n ", %16, %" #m "\n"
+#define MAD64_IND(n) MAD64I_##n
+#define MAD64I_0 MAD64I(0, 8)
+#define MAD64I_1 MAD64I(1, 9)
+#define MAD64I_2 MAD64I(2, 10)
+#define MAD64I_3 MAD64I(3, 11)
+#define MAD64I_4 MAD64I(4, 12)
+#define MAD64I_5 MAD64I(5, 13)
+#define MAD64I_6 MAD64I(6, 14)
+#define MAD64I_7 MAD64I(7, 15)
+#define MAD64_D(n) "v_mad_u64_u32 %8, vcc, %0, %16, %8\n"
+DEFINE_KERNEL(k_mad_u64_u32, , MAD64_IND, MAD64_D)
+
+// Two waves on one SIMD: waves 0-3 of a workgroup land on the four SIMDs, wave 4+ share them.
+// Every wave runs the PAIR round wave's instruction mix (8 alignbit/bfi, 4 bitop3, 3 lshl_add_u64,
+// 4 DPP adds per "round"); waves 0-3 at s_setprio 3 (as the round waves are), the rest at 0 and
+// `duty` of 4 iterations busy.  Reported: cycles per "round" of each wave -- what a round wave
+// loses when a helper wave shares its SIMD.
+__global__ __launch_bounds__(1024) void k_share(uint64_t* cycles, uint32_t* sink, int iters, int duty)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t r0 = threadIdx.x, r1 = r0 * 3 + 1, r2 = r0 ^ 0x55, r3 = r0 + 7, r4 = r0 * 5, r5 = r0 | 9, r6 = r0 - 3, r7 = r0 * 11;
+    uint32_t s0 = 13, s1 = r0 * 7 + 3;
+    uint64_t q0 = r0, q1 = r1, q2 = r2;
+    if (wave < 4) __builtin_amdgcn_s_setprio(3);
+    const int n = wave < 4 ? iters : (iters * duty) / 4;
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < n; ++it) {
+        asm volatile(
+            "v_alignbit_b32 %0, %1, %0, %12\n" "v_alignbit_b32 %1, %0, %1, %12\n"
+            "v_alignbit_b32 %2, %1, %0, %11\n" "v_alignbit_b32 %3, %0, %1, %11\n"
+            "v_bitop3_b32 %4, %0, %2, %5 bitop3:0x78\n" "v_bitop3_b32 %5, %1, %3, %4 bitop3:0x78\n"
+            "v_bitop3_b32 %0, %0, %2, %6 bitop3:0x96\n" "v_bitop3_b32 %1, %1, %3, %7 bitop3:0x96\n"
+            "v_bfi_b32 %6, %4, %2, %0\n" "v_bfi_b32 %7, %5, %3, %1\n"
+            "v_lshl_add_u64 %8, %8, 0, %9\n"
+            "v_alignbit_b32 %2, %1, %0, %12\n" "v_alignbit_b32 %3, %0, %1, %12\n"
+            "v_lshl_add_u64 %9, %9, 0, %10\n" "v_lshl_add_u64 %10, %10, 0, %8\n"
+            "v_add_co_u32_dpp %4, vcc, %6, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n"
+            "v_addc_co_u32_dpp %5, vcc, %7, %5, vcc row_half_mirror row_mask:0xf bank_mask:0x5\n"
+            "v_add_co_u32_dpp %4, vcc, %2, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n"
+            "v_addc_co_u32_dpp %5, vcc, %3, %5, vcc row_half_mirror row_mask:0xf bank_mask:0xa\n"
+            : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(q0), "+v"(q1), "+v"(q2)
+            : "v"(s0), "v"(s1) : "vcc");
+    }
+    uint64_t t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 16 + wave] = t1 - t0;
+    uint32_t acc = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7 ^ (uint32_t)(q0 ^ q1 ^ q2);
+    if (acc == 0x12345678) sink[0] = acc;
+}
+
+static void run_share(int nwaves, int duty, uint64_t* d_cycles, uint32_t* d_sink)
+{
+    const int iters = 20000, blocks = 256;
+    CHECK(hipMemset(d_cycles, 0, blocks * 16 * 8));
+    hipLaunchKernelGGL(k_share, dim3(blocks), dim3(64 * nwaves), 0, 0, d_cycles, d_sink, iters, duty);
+    hipLaunchKernelGGL(k_share, dim3(blocks), dim3(64 * nwaves), 0, 0, d_cycles, d_sink, iters, duty);
+    CHECK(hipDeviceSynchronize());
+    std::vector<uint64_t> h(blocks * 16);
+    CHECK(hipMemcpy(h.data(), d_cycles, blocks * 16 * 8, hipMemcpyDeviceToHost));
+    printf("k_share waves/WG=%d helper duty=%d/4: cycles per 19-instruction round, median over 256 CUs:", nwaves, duty);
+    for (int w = 0; w < nwaves; ++w) {
+        std::vector<uint64_t> c;
+        for (int b = 0; b < blocks; ++b) c.push_back(h[b * 16 + w]);
+        std::sort(c.begin(), c.end());
+        const int n = w < 4 ? iters : (iters * duty) / 4;
+        printf("  w%d=%.1f", w, (double)c[blocks / 2] / n);
+    }
+    printf("\n");
+}
+
 template <typename K>
 static void run(const char* name, K kern, int instr_per_loop, int waves_per_simd, uint64_t* d_cycles, uint32_t* d_sink)
 {
@@ -227,6 +338,16 @@ int main()
         RUN(k_dppxor_masked, 16);
         RUN(k_permlane32_swap, 16);
         RUN(k_cndmask, 16);
+        RUN(k_bitop3, 16);
+        RUN(k_xor_e64, 16);
+        RUN(k_add_u32_e32, 16);
+        RUN(k_add_u32_e64, 16);
+        RUN(k_fma_f32, 16);
+        RUN(k_add3_u32, 16);
+        RUN(k_mov_e32, 16);
+        RUN(k_dpp_row_ror8, 16);
+        RUN(k_dppadd_row_shr8, 16);
+        RUN(k_mad_u64_u32, 16);
         RUN(k_valu_plus_salu, 32);
         run("k_lds_mix(1ds+4valu)", k_lds_mix<false>, 20, w, d_cycles, d_sink);
         // per-iteration cost: kIters is not used by this kernel (2048 iterations): scale = 2048/kIters per "instr"
@@ -234,5 +355,10 @@ int main()
         run("lds+2barriers hop (cycles*4/iter)", k_lds_barrier_pingpong<true>, 1, w, d_cycles, d_sink);
         printf("\n");
     }
+    for (int nw : {4, 5, 6, 8})
+        for (int duty : {4, 2}) {
+            if (nw == 4 && duty != 4) continue;
+            run_share(nw, duty, d_cycles, d_sink);
+        }
     return 0;
 }

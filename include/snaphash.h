@@ -199,6 +199,37 @@ int snaphash_batch_end(snaphash_batch *b, size_t stream);
 int snaphash_batch_finish(snaphash_batch *b, uint8_t *digests /* n_streams * 64 */);
 void snaphash_batch_abort(snaphash_batch *b);
 
+/* ---- the data.tar.gz producer (fused with the hash pass: row f2) ---- */
+
+typedef struct snaphash_targz_stats { /* of the most recent snaphash_tar_create / snaphash_gzip_buffer */
+    uint64_t tar_bytes;     /* uncompressed stream */
+    uint64_t gz_bytes;      /* bytes written */
+    uint64_t members;       /* tar members */
+    uint64_t chunks;        /* 16 KiB deflate chunks */
+    uint64_t stored_chunks; /* of those, emitted as stored blocks (did not shrink) */
+    double deflate_ms;      /* deflate + concatenation kernels, HIP events */
+    double fill_ms;         /* assembling the tar stream in pinned memory (header records, parallel pread) */
+    double wall_ms;
+} snaphash_targz_stats;
+
+/* tarCreate (clickdeb/deb.go:261-344): walks source_dir (filepath.Walk order, Lstat; regular files,
+ * symlinks and directories only), skips every path that starts with exclude_prefix (NULL = none; Build
+ * passes <source_dir>/DEBIAN, deb.go:361-363), names members "./<relative path>", owner root/root, and
+ * writes the tar stream through a gzip member into tarname (must end in ".gz": the reference's ".xz"
+ * branch is an external tool).  The DEFLATE stream is produced on the GPU, block-parallel: it is
+ * format-compatible with, not byte-identical to, compress/gzip level 9 (archive-sha512 is defined over
+ * whatever bytes are produced, build.go:222).
+ * yaml_out != NULL fuses writeHashes into the same pass (row f2: every file is read ONCE): the SHA-512
+ * kernels hash each regular file out of the staged tar stream, the archive digest is taken over the
+ * bytes written, and *yaml_out receives hashes.yaml (snaphash_free); exclude_prefix must then be
+ * writeHashes' own rule.  archive_digest (may be NULL): the 64 raw bytes of SHA-512(tarname). */
+int snaphash_tar_create(snaphash_ctx *ctx, const char *tarname, const char *source_dir, const char *exclude_prefix,
+                        char **yaml_out, size_t *yaml_len, uint8_t *archive_digest);
+
+/* The compressor alone: one gzip member (RFC 1952) of a host buffer; *gz_out is malloc'd (snaphash_free). */
+int snaphash_gzip_buffer(snaphash_ctx *ctx, const void *data, size_t n, void **gz_out, size_t *gz_len);
+void snaphash_get_targz_stats(const snaphash_ctx *ctx, snaphash_targz_stats *out);
+
 /* ---- neighbouring scan: helpers.FilesAreEqual / DirUpdated -------- */
 
 /* helpers.FilesAreEqual (helpers/cmp.go:31-60), batched: equal[i] = 1 iff a[i] and b[i] both

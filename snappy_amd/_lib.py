@@ -28,6 +28,7 @@ EXPORTS = [
     "snaphash_fill_synthetic_device", "snaphash_strerror", "snaphash_last_error", "snaphash_get_stats",
     "snaphash_get_stats_ex", "snaphash_get_device_stats", "snaphash_tree_ex",
     "snaphash_batch_begin", "snaphash_batch_append", "snaphash_batch_end", "snaphash_batch_finish", "snaphash_batch_abort",
+    "snaphash_tar_create", "snaphash_gzip_buffer", "snaphash_get_targz_stats",
 ]
 FLAG_CHECK_GATHER, FLAG_NO_RCCL = 1, 2
 
@@ -51,6 +52,12 @@ class Stats(ctypes.Structure):
     _fields_ = [("bytes_hashed", ctypes.c_uint64), ("blocks", ctypes.c_uint64), ("streams", ctypes.c_uint64),
                 ("launches", ctypes.c_uint32), ("kernel_used", ctypes.c_uint32), ("kernel_ms", ctypes.c_double),
                 ("h2d_ms", ctypes.c_double), ("wall_ms", ctypes.c_double)]
+
+
+class TargzStats(ctypes.Structure):
+    _fields_ = [("tar_bytes", ctypes.c_uint64), ("gz_bytes", ctypes.c_uint64), ("members", ctypes.c_uint64),
+                ("chunks", ctypes.c_uint64), ("stored_chunks", ctypes.c_uint64), ("deflate_ms", ctypes.c_double),
+                ("fill_ms", ctypes.c_double), ("wall_ms", ctypes.c_double)]
 
 
 class Mismatch(ctypes.Structure):
@@ -135,6 +142,11 @@ def lib():
     L.snaphash_batch_finish.argtypes = [vp, vp]
     L.snaphash_batch_abort.argtypes = [vp]
     L.snaphash_batch_abort.restype = None
+    L.snaphash_tar_create.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(vp),
+                                      ctypes.POINTER(sz), ctypes.c_char_p]
+    L.snaphash_gzip_buffer.argtypes = [vp, vp, sz, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.snaphash_get_targz_stats.argtypes = [vp, ctypes.POINTER(TargzStats)]
+    L.snaphash_get_targz_stats.restype = None
     _lib = L
     return L
 
@@ -242,6 +254,35 @@ class Context:
             return ctypes.string_at(p.value, n.value)
         finally:
             lib().snaphash_free(p)
+
+    def gzip_buffer(self, data):
+        """One gzip member of `data`, DEFLATE on the GPU (row f3)."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        buf = (ctypes.c_char * max(len(data), 1)).from_buffer_copy(data if len(data) else b"\0")
+        self._check(lib().snaphash_gzip_buffer(self._h, ctypes.addressof(buf), len(data), ctypes.byref(p), ctypes.byref(n)))
+        try:
+            return ctypes.string_at(p.value, n.value)
+        finally:
+            lib().snaphash_free(p)
+
+    def tar_create(self, tarname, source_dir, exclude_prefix=None, with_hashes=False):
+        """tarCreate (clickdeb/deb.go:261-344).  with_hashes: also hashes.yaml from the same read.
+        -> (yaml bytes or None, archive digest (64 bytes))."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        dig = ctypes.create_string_buffer(64)
+        self._check(lib().snaphash_tar_create(self._h, os.fsencode(tarname), os.fsencode(source_dir),
+                                              os.fsencode(exclude_prefix) if exclude_prefix else None,
+                                              ctypes.byref(p) if with_hashes else None, ctypes.byref(n), dig))
+        try:
+            return (ctypes.string_at(p.value, n.value) if with_hashes else None), dig.raw
+        finally:
+            if with_hashes:
+                lib().snaphash_free(p)
+
+    def targz_stats(self):
+        s = TargzStats()
+        lib().snaphash_get_targz_stats(self._h, ctypes.byref(s))
+        return {f[0]: getattr(s, f[0]) for f in TargzStats._fields_}
 
     def batch(self, n_streams):
         """Streaming batch (row f2): feed chunks as another pass reads them."""

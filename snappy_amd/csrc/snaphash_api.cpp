@@ -31,10 +31,12 @@
 #include <memory>
 #include <mutex>
 
+#include "deflate_kernels.h"
 #include "hostpass.h"
 #include "hostsha.h"
 #include "sha512_core.h"
 #include "sha512_kernels.h"
+#include "tarpack.h"
 
 using namespace snaphash;
 
@@ -44,7 +46,7 @@ constexpr uint64_t kDefaultStaging = 256ull << 20;
 constexpr uint64_t kAlign = 256;          // placement of a segment inside a staging buffer
 constexpr uint32_t kTargetStreams = 4096; // streams per batch the engine aims for (keeps the kernel ahead of PCIe)
 
-struct EventPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; }; // kind 0 kernel, 1 h2d
+struct EventPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; }; // kind 0 SHA-512 kernels, 1 h2d, 2 deflate kernels
 
 struct Slot {
     uint8_t* h_buf = nullptr; // pinned host
@@ -92,6 +94,16 @@ struct DevCtx {
     uint8_t* d_equal = nullptr;
     size_t equal_cap = 0;
 
+    // block-parallel DEFLATE scratch (row f3): per-chunk output slots, sizes, offsets, compacted output
+    uint8_t* d_zslots = nullptr;
+    uint8_t* d_zout = nullptr;
+    uint32_t* d_zsizes = nullptr;
+    uint64_t* d_zprefix = nullptr;
+    uint32_t* h_zsizes = nullptr; // pinned
+    uint64_t* h_zprefix = nullptr;
+    uint8_t* h_zout = nullptr;
+    size_t z_chunks = 0;
+
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
     bool pending = false;
@@ -129,6 +141,7 @@ struct snaphash_ctx {
     size_t gather_cap = 0;          // rows (kmax) the gather buffers hold
     snaphash_stats stats{};
     snaphash_stats_ex ex{};
+    snaphash_targz_stats targz{};
     std::string last_error;
     snaphash_batch* open_batch = nullptr;
     DevCtx* d0() const { return dev[0].get(); }
@@ -178,7 +191,7 @@ void collect_events(DevCtx* c)
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) {
             if (c->ev_pool[i].kind == 0) c->stats.kernel_ms += ms;
-            else c->stats.h2d_ms += ms;
+            else if (c->ev_pool[i].kind == 1) c->stats.h2d_ms += ms;
         }
     }
     c->ev_used = 0;
@@ -218,7 +231,7 @@ int ensure_slots(DevCtx* c)
 {
     for (Slot& s : c->slot) {
         if (!s.h_buf) HIP_TRY(c, hipHostMalloc((void**)&s.h_buf, c->staging, hipHostMallocDefault));
-        if (!s.d_buf) HIP_TRY(c, hipMalloc((void**)&s.d_buf, c->staging));
+        if (!s.d_buf) HIP_TRY(c, hipMalloc((void**)&s.d_buf, c->staging + 256)); // slack: the deflate kernel peeks 3 bytes past a chunk
         if (!s.done) HIP_TRY(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         if (!s.copied) HIP_TRY(c, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
     }
@@ -847,6 +860,13 @@ static void destroy_dev(DevCtx* c)
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_digests) (void)hipFree(c->d_digests);
+    if (c->d_zslots) (void)hipFree(c->d_zslots);
+    if (c->d_zout) (void)hipFree(c->d_zout);
+    if (c->d_zsizes) (void)hipFree(c->d_zsizes);
+    if (c->d_zprefix) (void)hipFree(c->d_zprefix);
+    if (c->h_zsizes) (void)hipHostFree(c->h_zsizes);
+    if (c->h_zprefix) (void)hipHostFree(c->h_zprefix);
+    if (c->h_zout) (void)hipHostFree(c->h_zout);
     for (EventPair& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
@@ -1385,6 +1405,8 @@ void snaphash_batch_abort(snaphash_batch* b)
 }
 
 } // extern "C"
+
+#include "targz.inc"
 
 // ---- helpers.FilesAreEqual / DirUpdated (row f4) ----------------------------------------------
 

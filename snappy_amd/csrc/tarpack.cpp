@@ -1,0 +1,201 @@
+// tarpack.cpp -- see tarpack.h.  Host-only; no hashing, no compression here.
+#include "tarpack.h"
+
+#include <dirent.h>
+#include <errno.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+
+#include "../../include/snaphash.h"
+
+namespace snaphash {
+
+const uint8_t kGzipHeader[10] = {0x1f, 0x8b, 0x08, 0x00, 0x00, 0x00, 0x00, 0x00, 0x02, 0xff}; // deflate, no name/mtime, XFL=best, OS unknown
+
+// ---- filepath.Walk as tarCreate drives it (deb.go:283-341) ------------------------------------
+
+static int plan_rec(const std::string& path, size_t rootlen, const std::string& exclude_prefix, TarPlan& out, int* err_no,
+                    std::string* err_what)
+{
+    struct stat st;
+    if (lstat(path.c_str(), &st) != 0) { *err_no = errno; if (err_what) *err_what = path; return SNAPHASH_EIO; }
+    const bool supported = S_ISREG(st.st_mode) || S_ISLNK(st.st_mode) || S_ISDIR(st.st_mode); // deb.go:290-292
+    const bool excluded = !exclude_prefix.empty() && path.compare(0, exclude_prefix.size(), exclude_prefix) == 0; // deb.go:295-299
+    const bool is_root = path.size() == rootlen; // relativePath == "." (deb.go:309-312)
+    if (supported && !excluded && !is_root) {
+        TarMember m;
+        m.path = path;
+        m.name = "." + path.substr(rootlen); // deb.go:309
+        m.st_mode = st.st_mode;
+        m.mtime = (int64_t)st.st_mtime;
+        if (S_ISREG(st.st_mode)) { m.typeflag = '0'; m.size = (int64_t)st.st_size; }
+        else if (S_ISDIR(st.st_mode)) m.typeflag = '5';
+        else {
+            m.typeflag = '2';
+            char buf[4096];
+            const ssize_t n = readlink(path.c_str(), buf, sizeof buf); // os.Readlink, error ignored (deb.go:302)
+            if (n > 0) m.linkname.assign(buf, (size_t)n);
+        }
+        out.members.push_back(std::move(m));
+    }
+    if (!S_ISDIR(st.st_mode)) return SNAPHASH_OK;
+    DIR* d = opendir(path.c_str());
+    if (!d) { *err_no = errno; if (err_what) *err_what = path; return SNAPHASH_EIO; }
+    std::vector<std::string> names;
+    while (struct dirent* de = readdir(d)) {
+        if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
+        names.emplace_back(de->d_name);
+    }
+    closedir(d);
+    std::sort(names.begin(), names.end()); // sort.Strings: byte-wise
+    for (const std::string& n : names) {
+        int rc = plan_rec(path + "/" + n, rootlen, exclude_prefix, out, err_no, err_what);
+        if (rc) return rc;
+    }
+    return SNAPHASH_OK;
+}
+
+int tar_plan(const char* source_dir, const std::string& exclude_prefix, TarPlan& out, int* err_no, std::string* err_what)
+{
+    std::string root(source_dir);
+    while (root.size() > 1 && root.back() == '/') root.pop_back();
+    out.members.clear();
+    int e = 0;
+    int rc = plan_rec(root, root.size(), exclude_prefix, out, &e, err_what);
+    if (err_no) *err_no = e;
+    if (rc) return rc;
+    uint64_t off = 0;
+    for (TarMember& m : out.members) {
+        m.hdr_off = off;
+        m.data_off = off + 512;
+        off += 512 + (((uint64_t)m.size + 511) & ~(uint64_t)511); // content is padded to the 512-byte record
+    }
+    out.total = off + 1024; // tar.Writer.Close: two zero blocks
+    return SNAPHASH_OK;
+}
+
+// ---- ustar header ---------------------------------------------------------------------------
+
+static void octal(uint8_t* f, int width, uint64_t v) // width-1 digits, zero padded, NUL terminated
+{
+    for (int i = width - 2; i >= 0; --i) { f[i] = (uint8_t)('0' + (v & 7)); v >>= 3; }
+    f[width - 1] = 0;
+}
+
+int tar_header(const TarMember& m, uint8_t h[512])
+{
+    memset(h, 0, 512);
+    // name: up to 100 bytes, or prefix (<= 155) + "/" + name split at a slash
+    const std::string& nm = m.name;
+    if (nm.size() <= 100) {
+        memcpy(h, nm.data(), nm.size());
+    } else {
+        size_t cut = std::string::npos;
+        for (size_t i = std::min<size_t>(nm.size() - 1, 155); i > 0; --i)
+            if (nm[i] == '/' && nm.size() - i - 1 <= 100 && i <= 155) { cut = i; break; }
+        if (cut == std::string::npos || nm.size() - cut - 1 == 0) return SNAPHASH_ENAME;
+        memcpy(h + 345, nm.data(), cut);
+        memcpy(h, nm.data() + cut + 1, nm.size() - cut - 1);
+    }
+    if (m.linkname.size() > 100) return SNAPHASH_ENAME;
+    // mode: permission bits + setuid/setgid/sticky + the file type bits, as tar.FileInfoHeader fills it
+    uint64_t mode = m.st_mode & 07777;
+    if (m.typeflag == '0') mode |= 0100000;
+    else if (m.typeflag == '5') mode |= 040000;
+    else mode |= 0120000;
+    octal(h + 100, 8, mode);
+    octal(h + 108, 8, 0); // uid: all files belong to root (deb.go:316-319)
+    octal(h + 116, 8, 0); // gid
+    if ((uint64_t)m.size >= (1ull << 33)) return SNAPHASH_EINVAL; // 11 octal digits
+    octal(h + 124, 12, m.typeflag == '0' ? (uint64_t)m.size : 0);
+    octal(h + 136, 12, m.mtime < 0 ? 0 : (uint64_t)m.mtime);
+    memset(h + 148, ' ', 8); // checksum field counts as spaces
+    h[156] = (uint8_t)m.typeflag;
+    memcpy(h + 157, m.linkname.data(), m.linkname.size());
+    memcpy(h + 257, "ustar", 6); // magic "ustar\0"
+    h[263] = '0'; h[264] = '0';  // version "00"
+    memcpy(h + 265, "root", 4);  // uname
+    memcpy(h + 297, "root", 4);  // gname
+    octal(h + 329, 8, 0);        // devmajor
+    octal(h + 337, 8, 0);        // devminor
+    unsigned sum = 0;
+    for (int i = 0; i < 512; ++i) sum += h[i];
+    octal(h + 148, 7, sum); // six digits + NUL, then the space that is already there
+    h[155] = ' ';
+    return SNAPHASH_OK;
+}
+
+// ---- CRC-32 -----------------------------------------------------------------------------------
+
+static uint32_t g_crc[8][256];
+static bool g_crc_ready = false;
+static void crc_init()
+{
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        g_crc[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t) g_crc[t][i] = g_crc[0][g_crc[t - 1][i] & 0xff] ^ (g_crc[t - 1][i] >> 8);
+    g_crc_ready = true;
+}
+namespace { struct CrcInit { CrcInit() { crc_init(); } } g_crc_init; }
+
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n)
+{
+    if (!g_crc_ready) crc_init();
+    uint32_t c = ~crc;
+    while (n && ((uintptr_t)p & 7)) { c = g_crc[0][(c ^ *p++) & 0xff] ^ (c >> 8); --n; }
+    while (n >= 8) {
+        uint64_t v;
+        memcpy(&v, p, 8);
+        const uint32_t lo = (uint32_t)v ^ c, hi = (uint32_t)(v >> 32);
+        c = g_crc[7][lo & 0xff] ^ g_crc[6][(lo >> 8) & 0xff] ^ g_crc[5][(lo >> 16) & 0xff] ^ g_crc[4][lo >> 24] ^
+            g_crc[3][hi & 0xff] ^ g_crc[2][(hi >> 8) & 0xff] ^ g_crc[1][(hi >> 16) & 0xff] ^ g_crc[0][hi >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = g_crc[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+    return ~c;
+}
+
+// CRC of a concatenation from the CRCs of its parts: multiply crc1 by x^(8*len2) modulo the polynomial
+// (square-and-multiply over GF(2) 32x32 matrices), then xor crc2.
+static uint32_t gf2_times(const uint32_t* mat, uint32_t vec)
+{
+    uint32_t sum = 0;
+    for (int i = 0; vec; vec >>= 1, ++i)
+        if (vec & 1) sum ^= mat[i];
+    return sum;
+}
+static void gf2_square(uint32_t* sq, const uint32_t* mat)
+{
+    for (int n = 0; n < 32; ++n) sq[n] = gf2_times(mat, mat[n]);
+}
+uint32_t crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
+{
+    if (len2 == 0) return crc1;
+    uint32_t even[32], odd[32];
+    odd[0] = 0xEDB88320u; // the operator for one zero bit
+    uint32_t row = 1;
+    for (int n = 1; n < 32; ++n) { odd[n] = row; row <<= 1; }
+    gf2_square(even, odd); // two zero bits
+    gf2_square(odd, even); // four
+    do {
+        gf2_square(even, odd); // first pass: one zero byte
+        if (len2 & 1) crc1 = gf2_times(even, crc1);
+        len2 >>= 1;
+        if (!len2) break;
+        gf2_square(odd, even);
+        if (len2 & 1) crc1 = gf2_times(odd, crc1);
+        len2 >>= 1;
+    } while (len2);
+    return crc1 ^ crc2;
+}
+
+} // namespace snaphash

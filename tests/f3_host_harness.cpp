@@ -1,0 +1,131 @@
+// Test-only (CPU): (1) a serial model of deflate_chunks_kernel -- same chunking, hash, greedy parse,
+// token encoder (snappy_amd/csrc/deflate_core.h) and framing -- so that the code tables and the
+// byte-aligned chunk framing are checked against zlib before the kernel runs on a GPU; (2) the host
+// half of the tar producer (tarpack.cpp): plan + ustar headers + CRC-32.  Not part of the product.
+#include <fcntl.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include "../snappy_amd/csrc/deflate_core.h"
+#include "../snappy_amd/csrc/tarpack.cpp"
+
+using namespace snaphash;
+
+namespace {
+constexpr uint32_t kChunk = 16384, kHashBits = 12;
+
+struct BitW {
+    std::vector<uint8_t>& o;
+    uint64_t acc = 0;
+    uint32_t n = 0;
+    explicit BitW(std::vector<uint8_t>& out) : o(out) {}
+    void put(uint32_t bits, uint32_t nb) { acc |= (uint64_t)bits << n; n += nb; while (n >= 8) { o.push_back((uint8_t)acc); acc >>= 8; n -= 8; } }
+    void align() { if (n) { o.push_back((uint8_t)acc); acc = 0; n = 0; } }
+};
+
+uint32_t ld32(const uint8_t* p, const uint8_t* end) // like the kernel: bytes past the buffer read as padding
+{
+    uint32_t v = 0;
+    for (int k = 0; k < 4; ++k) if (p + k < end) v |= (uint32_t)p[k] << (8 * k);
+    return v;
+}
+
+void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, std::vector<uint8_t>& out)
+{
+    std::vector<uint8_t> z;
+    BitW w(z);
+    w.put(2, 3);
+    std::vector<uint16_t> tab(1u << kHashBits, 0);
+    uint32_t skip_until = 0;
+    for (uint32_t p0 = 0; p0 < len; p0 += 64) {
+        uint32_t mlen[64] = {0}, dist[64] = {0}, word[64] = {0};
+        uint32_t cand[64] = {0};
+        const uint32_t tile_n = len - p0 < 64 ? len - p0 : 64;
+        for (uint32_t i = 0; i < tile_n; ++i) { // all lanes read the table before any lane writes it
+            const uint32_t pos = p0 + i;
+            word[i] = ld32(src + pos, bufend);
+            if (pos + 4 <= len) cand[i] = tab[(word[i] * 0x9E3779B1u) >> (32 - kHashBits)];
+        }
+        for (uint32_t i = 0; i < tile_n; ++i) {
+            const uint32_t pos = p0 + i;
+            if (pos + 4 <= len) tab[(word[i] * 0x9E3779B1u) >> (32 - kHashBits)] = (uint16_t)(pos + 1);
+        }
+        for (uint32_t i = 0; i < tile_n; ++i) {
+            const uint32_t pos = p0 + i;
+            if (pos + 4 > len || !cand[i]) continue;
+            const uint32_t cp = cand[i] - 1, maxl = len - pos < 258 ? len - pos : 258;
+            uint32_t l = 0;
+            while (l < maxl && src[pos + l] == src[cp + l]) ++l;
+            if (l >= 4) { mlen[i] = l; dist[i] = pos - cp; }
+        }
+        uint32_t rel = skip_until > p0 ? skip_until - p0 : 0;
+        while (rel < tile_n) {
+            uint32_t bits, nb;
+            if (mlen[rel] >= 4) { enc_match(mlen[rel], dist[rel], bits, nb); w.put(bits, nb); rel += mlen[rel]; }
+            else { enc_literal(word[rel] & 0xff, bits, nb); w.put(bits, nb); rel += 1; }
+        }
+        skip_until = p0 + rel;
+    }
+    w.put(0, 7);  // end of block
+    w.put(0, 3);  // empty stored block
+    w.align();
+    z.push_back(0); z.push_back(0); z.push_back(0xff); z.push_back(0xff);
+    if (z.size() >= len + 5u) {
+        out.push_back(0);
+        out.push_back((uint8_t)len); out.push_back((uint8_t)(len >> 8));
+        out.push_back((uint8_t)~len); out.push_back((uint8_t)(~len >> 8));
+        out.insert(out.end(), src, src + len);
+    } else {
+        out.insert(out.end(), z.begin(), z.end());
+    }
+}
+} // namespace
+
+extern "C" {
+
+// -> malloc'd gzip member; model of snaphash_gzip_buffer's output format
+uint8_t* f3_model_gzip(const uint8_t* in, size_t n, size_t* out_len)
+{
+    std::vector<uint8_t> out(kGzipHeader, kGzipHeader + 10);
+    for (size_t off = 0; off < n; off += kChunk) deflate_chunk(in + off, (uint32_t)(n - off < kChunk ? n - off : kChunk), in + n, out);
+    out.push_back(0x03); out.push_back(0x00);
+    const uint32_t crc = crc32_update(0, in, n);
+    for (int k = 0; k < 4; ++k) out.push_back((uint8_t)(crc >> (8 * k)));
+    for (int k = 0; k < 4; ++k) out.push_back((uint8_t)((uint32_t)n >> (8 * k)));
+    uint8_t* p = (uint8_t*)malloc(out.size());
+    memcpy(p, out.data(), out.size());
+    *out_len = out.size();
+    return p;
+}
+
+uint32_t f3_crc32(uint32_t crc, const uint8_t* p, size_t n) { return crc32_update(crc, p, n); }
+uint32_t f3_crc32_combine(uint32_t a, uint32_t b, uint64_t len2) { return crc32_combine(a, b, len2); }
+
+// the whole tar stream of a directory, as the producer lays it out (host reads; tests only)
+int f3_tar_stream(const char* dir, const char* exclude_prefix, uint8_t** out, size_t* out_len)
+{
+    TarPlan plan;
+    int en = 0;
+    std::string what;
+    int rc = tar_plan(dir, exclude_prefix ? exclude_prefix : "", plan, &en, &what);
+    if (rc) return rc;
+    uint8_t* buf = (uint8_t*)calloc(plan.total ? plan.total : 1, 1);
+    for (const TarMember& m : plan.members) {
+        rc = tar_header(m, buf + m.hdr_off);
+        if (rc) { free(buf); return rc; }
+        if (m.typeflag == '0' && m.size) {
+            const int fd = open(m.path.c_str(), O_RDONLY);
+            if (fd < 0 || pread(fd, buf + m.data_off, (size_t)m.size, 0) != (ssize_t)m.size) { if (fd >= 0) close(fd); free(buf); return -3; }
+            close(fd);
+        }
+    }
+    *out = buf;
+    *out_len = plan.total;
+    return 0;
+}
+void f3_free(void* p) { free(p); }
+}

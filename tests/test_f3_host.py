@@ -1,0 +1,155 @@
+"""Row f3 on the CPU: the host half of the data.tar.gz producer (snappy_amd/csrc/tarpack.cpp: tarCreate's
+walk and member rules, ustar headers, CRC-32) and a serial model of the DEFLATE kernel's format (same
+token encoder header, same chunk framing) checked against zlib, gzip and tarfile.  The kernel itself is
+checked on the GPU (tests/test_gpu_f3.py)."""
+import ctypes
+import gzip
+import io
+import os
+import stat
+import subprocess
+import tarfile
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def f3(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("f3") / "libf3host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "tests", "f3_host_harness.cpp")])
+    L = ctypes.CDLL(so)
+    L.f3_model_gzip.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.f3_model_gzip.restype = ctypes.c_void_p
+    L.f3_crc32.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+    L.f3_crc32.restype = ctypes.c_uint32
+    L.f3_crc32_combine.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]
+    L.f3_crc32_combine.restype = ctypes.c_uint32
+    L.f3_tar_stream.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.f3_free.argtypes = [ctypes.c_void_p]
+    return L
+
+
+def sample_inputs():
+    rng = np.random.default_rng(7)
+    text = (b"The quick brown fox jumps over the lazy dog. " * 3000)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(500)]
+    prose = b" ".join(words[int(i)] for i in rng.integers(0, 500, size=40000))
+    return {
+        "empty": b"", "one": b"x", "three": b"abc", "four": b"abcd", "zeros": bytes(100000), "ff": b"\xff" * 70000,
+        "random": rng.integers(0, 256, size=50000, dtype=np.uint8).tobytes(), "text": text, "prose": prose,
+        "chunk-1": prose[:16383], "chunk": prose[:16384], "chunk+1": prose[:16385], "two chunks+3": prose[:32771],
+        "long run then noise": bytes(300) + rng.integers(0, 256, size=20000, dtype=np.uint8).tobytes() + bytes(5000),
+        "high bytes": bytes(rng.integers(144, 256, size=40000, dtype=np.uint8)),
+    }
+
+
+def test_model_of_the_deflate_kernel_is_valid_gzip(f3):
+    """Every sample decompresses (zlib's inflater and the gzip module) to exactly the input; compressible
+    inputs shrink; incompressible ones cost 5 bytes per 16 KiB chunk (stored blocks)."""
+    for name, data in sample_inputs().items():
+        n = ctypes.c_size_t()
+        p = f3.f3_model_gzip(data, len(data), ctypes.byref(n))
+        gz = ctypes.string_at(p, n.value)
+        f3.f3_free(p)
+        assert gz[:10] == bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 0xff]), name
+        assert gzip.decompress(gz) == data, name
+        assert zlib.decompressobj(-15).decompress(gz[10:-8]) == data, name
+        assert int.from_bytes(gz[-8:-4], "little") == zlib.crc32(data) and int.from_bytes(gz[-4:], "little") == len(data) & 0xffffffff
+        if name in ("zeros", "ff", "text"):
+            assert len(gz) < len(data) // 8, (name, len(gz), len(data))
+        if name == "prose":  # random words: single-candidate greedy LZ77 + fixed codes, ~0.56
+            assert len(gz) < len(data) * 2 // 3, (name, len(gz), len(data))
+        if name in ("random", "high bytes"):
+            assert len(gz) <= len(data) + 5 * (len(data) // 16384 + 1) + 20, (name, len(gz))
+
+
+def test_crc32_and_combine_match_zlib(f3):
+    rng = np.random.default_rng(8)
+    blob = rng.integers(0, 256, size=300000, dtype=np.uint8).tobytes()
+    for a, b in ((0, 0), (0, 1), (1, 7), (13, 100000), (8, 8), (100001, 199999), (0, 300000)):
+        assert f3.f3_crc32(0, blob[a:b], b - a) == zlib.crc32(blob[a:b])
+    for cut in (0, 1, 4096, 150000, 299999, 300000):
+        c1, c2 = zlib.crc32(blob[:cut]), zlib.crc32(blob[cut:])
+        assert f3.f3_crc32_combine(c1, c2, len(blob) - cut) == zlib.crc32(blob)
+
+
+def _make_tree(root):
+    os.makedirs(os.path.join(root, "usr", "bin"))
+    os.makedirs(os.path.join(root, "meta"))
+    os.makedirs(os.path.join(root, "DEBIAN"))
+    os.makedirs(os.path.join(root, "DEBIAN-extra"))
+    os.makedirs(os.path.join(root, "empty-dir"))
+    files = {"usr/bin/foo": b"foo", "meta/package.yaml": b"name: foo", "DEBIAN/control": b"Package: foo\n",
+             "DEBIAN-extra/x": b"skipped too: the rule is a string prefix", "a-b": b"", "big.bin": os.urandom(70001),
+             "exactly512": bytes(512), "usr/bin/" + "n" * 90: b"long name still fits"}
+    for rel, data in files.items():
+        with open(os.path.join(root, rel), "wb") as f:
+            f.write(data)
+    os.chmod(os.path.join(root, "usr/bin/foo"), 0o755)
+    os.chmod(os.path.join(root, "meta/package.yaml"), 0o640)
+    os.symlink("foo", os.path.join(root, "usr", "bin", "link"))
+    os.symlink("/dsafdsafsadf", os.path.join(root, "broken-link"))
+    os.mkfifo(os.path.join(root, "a-fifo"))  # not regular/symlink/dir: tarCreate skips it (deb.go:290-292)
+    return files
+
+
+def test_tar_stream_matches_tarcreate_rules(f3, tmp_path):
+    """The producer's tar stream through Python's tarfile: members, order, names, types, modes, owner, sizes,
+    link targets and contents are what tarCreate would write (clickdeb/deb.go:283-341); the reference's own
+    test expectations (deb_test.go: './usr/bin/foo' listed, nothing under DEBIAN) hold."""
+    root = str(tmp_path / "src")
+    os.makedirs(root)
+    files = _make_tree(root)
+    out, n = ctypes.c_void_p(), ctypes.c_size_t()
+    assert f3.f3_tar_stream(root.encode(), (root + "/DEBIAN").encode(), ctypes.byref(out), ctypes.byref(n)) == 0
+    stream = ctypes.string_at(out.value, n.value)
+    f3.f3_free(out)
+    assert len(stream) % 512 == 0 and stream[-1024:] == bytes(1024)
+    tf = tarfile.open(fileobj=io.BytesIO(stream), mode="r:")
+    members = tf.getmembers()
+    names = [m.name for m in members]
+    want = []
+
+    def walk(d, rel):  # filepath.Walk: pre-order, byte-wise sorted per directory
+        for name in sorted(os.listdir(d), key=os.fsencode):
+            p, r = os.path.join(d, name), rel + "/" + name
+            if p.startswith(root + "/DEBIAN"):
+                continue
+            st = os.lstat(p)
+            if stat.S_ISREG(st.st_mode) or stat.S_ISLNK(st.st_mode) or stat.S_ISDIR(st.st_mode):
+                want.append(("." + r, st))
+            if stat.S_ISDIR(st.st_mode):
+                walk(p, r)
+    walk(root, "")
+    assert names == [w[0] for w in want]
+    assert "./usr/bin/foo" in names and not any("DEBIAN" in x for x in names) and "./a-fifo" not in names
+    for m, (name, st) in zip(members, want):
+        assert (m.uid, m.gid, m.uname, m.gname) == (0, 0, "root", "root"), name
+        assert m.mtime == int(st.st_mtime), name
+        assert m.mode & 0o7777 == stat.S_IMODE(st.st_mode), name
+        if stat.S_ISREG(st.st_mode):
+            assert m.isreg() and m.size == st.st_size and tf.extractfile(m).read() == files[name[2:]], name
+        elif stat.S_ISDIR(st.st_mode):
+            assert m.isdir() and m.size == 0, name
+        else:
+            assert m.issym() and m.linkname == os.readlink(os.path.join(root, name[2:])), name
+    # raw header fields as archive/tar of the reference's era writes them
+    h = stream[:512]
+    assert h[257:265] == b"ustar\x0000" and h[100:108] == b"0100644\x00"[:8] or h[100:107].isdigit()
+    assert h[108:116] == b"0000000\x00" and h[265:269] == b"root"
+    # coreutils tar agrees
+    lst = subprocess.run(["tar", "-tf", "-"], input=stream, stdout=subprocess.PIPE, check=True).stdout.decode().split("\n")
+    assert [x.rstrip("/") for x in lst if x] == names
+
+
+def test_tar_name_too_long_is_refused(f3, tmp_path):
+    root = str(tmp_path / "s")
+    os.makedirs(root)
+    open(os.path.join(root, "x" * 101), "w").close()  # no slash to split at: does not fit ustar
+    out, n = ctypes.c_void_p(), ctypes.c_size_t()
+    assert f3.f3_tar_stream(root.encode(), None, ctypes.byref(out), ctypes.byref(n)) == -6  # SNAPHASH_ENAME

@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # measured ceilings of this implementation (profiles/); refreshed per round
-VALU_SATURATED_GBPS = float(os.environ.get("SNAPHASH_VALU_CEILING_GBPS", "1070"))
+VALU_SATURATED_GBPS = float(os.environ.get("SNAPHASH_VALU_CEILING_GBPS", "1215"))
 
 
 def parse_args():
@@ -298,6 +298,26 @@ def main():
                     "ms_per_step": round(j2["elapsed"] / nrep * 1e3, 4), "steps": nrep}
         del j2
 
+    # ---- N > 1: the same tree through ONE process and the C ABI's device list (what the Go caller reaches over
+    # cgo): in-library LPT shards + single-process RCCL gather.  A child process with a time limit: the headline
+    # line never depends on it. ----------------------------------------------------------------------------------
+    inlib = None
+    if world > 1 and rank == 0 and os.environ.get("SNAPHASH_BENCH_NO_INLIB") != "1" and args.workload in ("C1", "C2", "C5"):
+        import subprocess
+        try:
+            env = dict(os.environ)
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK",
+                      "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "inlib_multigpu.py"), args.workload, "-1"],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, env=env)
+            lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            inlib = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
+        except Exception as e:  # a time-out or a missing RCCL must not cost the headline
+            inlib = {"error": repr(e)[:400]}
+    if use_dist:
+        dist.barrier()
+
     # ---- parity spot check of the timed path, outside the timed region ------------------
     digests = job["digests"]
     parity = None
@@ -378,6 +398,10 @@ def main():
         }
         if side_leg is not None:
             line["other_scaling_leg"] = side_leg
+        if inlib is not None:
+            if "sha512_of_digest_vector" in inlib:
+                inlib["same_digest_vector_as_the_timed_path"] = inlib["sha512_of_digest_vector"] == parity["sha512_of_digest_vector"]
+            line["in_library_multi_gpu"] = inlib
         if end_to_end is not None:
             line["end_to_end"] = end_to_end
         if cpu is not None:

@@ -37,17 +37,59 @@ void host_sha512_resume(HostSha& s, const uint64_t H[8], uint64_t total_prev)
     s.ntail = 0;
 }
 
-static inline void block(uint64_t H[8], const uint8_t* p)
+// One 128-byte block: FIPS 180-4 sec. 6.4.2, rounds fully unrolled over a 16-word rolling schedule.
+// (Same function as compress_block in sha512_core.h; spelled for a host core: native 64-bit rotates,
+// and a BMI2 clone where the CPU has rorx.)
+#define HS_ROTR(x, n) (((x) >> (n)) | ((x) << (64 - (n))))
+#define HS_S0(x) (HS_ROTR(x, 28) ^ HS_ROTR(x, 34) ^ HS_ROTR(x, 39))
+#define HS_S1(x) (HS_ROTR(x, 14) ^ HS_ROTR(x, 18) ^ HS_ROTR(x, 41))
+#define HS_s0(x) (HS_ROTR(x, 1) ^ HS_ROTR(x, 8) ^ ((x) >> 7))
+#define HS_s1(x) (HS_ROTR(x, 19) ^ HS_ROTR(x, 61) ^ ((x) >> 6))
+#define HS_RND(a, b, c, d, e, f, g, h, kw)                                   \
+    do {                                                                    \
+        const uint64_t t1_ = h + HS_S1(e) + (g ^ (e & (f ^ g))) + (kw);      \
+        const uint64_t t2_ = HS_S0(a) + ((a & b) | (c & (a | b)));          \
+        d += t1_;                                                           \
+        h = t1_ + t2_;                                                      \
+    } while (0)
+
+__attribute__((target_clones("default", "bmi2"))) static void blocks(uint64_t H[8], const uint8_t* p, size_t nblocks)
 {
-    uint64_t w[16];
-    for (int k = 0; k < 16; ++k) {
-        uint32_t d0, d1;
-        memcpy(&d0, p + 8 * k, 4);
-        memcpy(&d1, p + 8 * k + 4, 4);
-        w[k] = be64(d0, d1);
+    uint64_t a = H[0], b = H[1], c = H[2], d = H[3], e = H[4], f = H[5], g = H[6], h = H[7];
+    for (; nblocks; --nblocks, p += 128) {
+        uint64_t w[16];
+        for (int k = 0; k < 16; ++k) {
+            uint64_t v;
+            memcpy(&v, p + 8 * k, 8);
+            w[k] = __builtin_bswap64(v);
+        }
+        const uint64_t sa = a, sb = b, sc = c, sd = d, se = e, sf = f, sg = g, sh = h;
+        for (int t = 0; t < 80; t += 16) {
+            if (t)
+                for (int k = 0; k < 16; ++k) w[k] += HS_s1(w[(k + 14) & 15]) + w[(k + 9) & 15] + HS_s0(w[(k + 1) & 15]);
+            const uint64_t* K = K512 + t;
+            HS_RND(a, b, c, d, e, f, g, h, K[0] + w[0]);
+            HS_RND(h, a, b, c, d, e, f, g, K[1] + w[1]);
+            HS_RND(g, h, a, b, c, d, e, f, K[2] + w[2]);
+            HS_RND(f, g, h, a, b, c, d, e, K[3] + w[3]);
+            HS_RND(e, f, g, h, a, b, c, d, K[4] + w[4]);
+            HS_RND(d, e, f, g, h, a, b, c, K[5] + w[5]);
+            HS_RND(c, d, e, f, g, h, a, b, K[6] + w[6]);
+            HS_RND(b, c, d, e, f, g, h, a, K[7] + w[7]);
+            HS_RND(a, b, c, d, e, f, g, h, K[8] + w[8]);
+            HS_RND(h, a, b, c, d, e, f, g, K[9] + w[9]);
+            HS_RND(g, h, a, b, c, d, e, f, K[10] + w[10]);
+            HS_RND(f, g, h, a, b, c, d, e, K[11] + w[11]);
+            HS_RND(e, f, g, h, a, b, c, d, K[12] + w[12]);
+            HS_RND(d, e, f, g, h, a, b, c, K[13] + w[13]);
+            HS_RND(c, d, e, f, g, h, a, b, K[14] + w[14]);
+            HS_RND(b, c, d, e, f, g, h, a, K[15] + w[15]);
+        }
+        a += sa; b += sb; c += sc; d += sd; e += se; f += sf; g += sg; h += sh;
     }
-    compress_block(H, w, true, K512);
+    H[0] = a; H[1] = b; H[2] = c; H[3] = d; H[4] = e; H[5] = f; H[6] = g; H[7] = h;
 }
+static inline void block(uint64_t H[8], const uint8_t* p) { blocks(H, p, 1); }
 
 void host_sha512_update(HostSha& s, const uint8_t* p, size_t n)
 {
@@ -62,7 +104,12 @@ void host_sha512_update(HostSha& s, const uint8_t* p, size_t n)
         block(s.H, s.tail);
         s.ntail = 0;
     }
-    for (; n >= 128; p += 128, n -= 128) block(s.H, p);
+    if (n >= 128) {
+        const size_t nb = n >> 7;
+        blocks(s.H, p, nb);
+        p += nb << 7;
+        n &= 127;
+    }
     if (n) {
         memcpy(s.tail, p, n);
         s.ntail = (uint32_t)n;

@@ -135,6 +135,7 @@ struct snaphash_batch;
 struct snaphash_ctx {
     std::vector<std::unique_ptr<DevCtx>> dev;
     uint32_t host_threads = 0;
+    double host_rate = 0.40e9; // bytes/s of one host thread's SHA-512, measured at init when host_threads > 0
     uint32_t flags = 0;
     Rccl rccl;
     std::vector<uint8_t*> d_gather; // per device: n_devices * kmax * 64 bytes
@@ -607,13 +608,31 @@ int gather_digest_slabs(snaphash_ctx* x, const std::vector<size_t>& cnt, size_t 
 // ---- hybrid scheduling (opt-in): which streams finish on host threads ---------------------
 // Rates of the two engines for ONE stream (measured on MI355X, DESIGN.md sec. 4 / profiles): the GPU
 // advances a lone stream at kGpuStreamRate whatever surrounds it, a host core at kHostRate.
-constexpr double kGpuStreamRate = 38e6;
-constexpr double kHostRate = 0.45e9;
+constexpr double kGpuStreamRate = 39e6;
 constexpr double kGpuAggregate = 40e9; // PCIe-inclusive rate of one device's staging engine
+
+// bytes per second of the library's host SHA-512 on one core of THIS box (hosts differ 3x): timed once,
+// on a 2 MiB buffer, when a ctx with host_threads > 0 is created
+double measure_host_rate()
+{
+    std::vector<uint8_t> buf(2u << 20, 0x5a);
+    HostSha hs;
+    uint8_t out[64];
+    double best = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        host_sha512_init(hs);
+        const double t0 = now_ms();
+        host_sha512_update(hs, buf.data(), buf.size());
+        host_sha512_final(hs, out);
+        const double dt = (now_ms() - t0) * 1e-3;
+        if (dt > 0) best = std::max(best, (double)buf.size() / dt);
+    }
+    return best > 50e6 ? best : 0.40e9;
+}
 
 // Streams sorted longest first; moves the longest to the host pool while that shortens the modelled
 // makespan max(GPU, host).  Returns per-stream 1 = host.
-std::vector<uint8_t> plan_host_streams(const std::vector<Source>& src, unsigned threads, size_t ndev)
+std::vector<uint8_t> plan_host_streams(const std::vector<Source>& src, unsigned threads, size_t ndev, double host_rate)
 {
     const size_t n = src.size();
     std::vector<uint8_t> on_host(n, 0);
@@ -634,7 +653,7 @@ std::vector<uint8_t> plan_host_streams(const std::vector<Source>& src, unsigned 
     double host_makespan = 0, best = gpu_time(0);
     size_t best_k = 0;
     for (size_t k = 0; k < n; ++k) {
-        const double t = pool.top() + (double)src[order[k]].len / kHostRate;
+        const double t = pool.top() + (double)src[order[k]].len / host_rate;
         pool.pop();
         pool.push(t);
         host_makespan = std::max(host_makespan, t);
@@ -685,7 +704,7 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     if (n == 0) return SNAPHASH_OK;
     const size_t nd = x->dev.size();
     for (Source& s : src) s.gpu_len = s.len;
-    const std::vector<uint8_t> on_host = plan_host_streams(src, x->host_threads, nd);
+    const std::vector<uint8_t> on_host = plan_host_streams(src, x->host_threads, nd, x->host_rate);
 
     // GPU part: LPT over the devices by SHA-512 block count (deterministic)
     std::vector<uint32_t> gidx;
@@ -899,6 +918,7 @@ int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
     std::unique_ptr<snaphash_ctx> x(new (std::nothrow) snaphash_ctx());
     if (!x) return SNAPHASH_ENOMEM;
     if (v2) { x->host_threads = std::min<uint32_t>(cfg->host_threads, 256); x->flags = cfg->flags; }
+    if (x->host_threads) x->host_rate = measure_host_rate();
     for (size_t k = 0; k < devs.size(); ++k) {
         const int dev = devs[k];
         if (dev < 0 || dev >= ndev) {

@@ -1,0 +1,11 @@
+#!/bin/bash
+# rocprofv3 kernel trace of the fused Build pass (row f3): per-kernel time of deflate_chunks_kernel,
+# deflate_compact_kernel and the SHA-512 kernels.  usage: tools/profile_targz.sh <outdir-under-gpurun_out> [kind] [MiB]
+set -o pipefail
+OUT="$GRAFT_REPO_ROOT/gpurun_out/$1"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$GRAFT_REPO_ROOT/tools/targz_bench.py" "${2:-text}" "${3:-1024}" > "$OUT/trace.log" 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$GRAFT_REPO_ROOT/tools/targz_bench.py" "${2:-text}" "${3:-1024}" > "$OUT/pmc_fetch.log" 2>&1 || exit 2
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$GRAFT_REPO_ROOT/tools/targz_bench.py" "${2:-text}" "${3:-1024}" > "$OUT/pmc_write.log" 2>&1 || exit 3
+find "$OUT" -name "*.csv" -size +8M -delete
+exit 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a tools/profile_bench.sh output directory into tracked files under profiles/.
 
-usage: tools/summarize_prof.py gpurun_out/<dir> <tag>      (e.g. r01_wide_C2)
+usage: tools/summarize_prof.py gpurun_out/<dir> <tag> [workload]     (e.g. r02_pair_C2 C2)
 Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim),
 profiles/<tag>_pmc.json (per-launch means of every counter for the sha512 kernel, with
 the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applied in `hbm_bytes_per_launch`)
@@ -16,6 +16,7 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "C2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -42,7 +43,15 @@ if "FETCH_SIZE" in pmc:
     write = pmc.get("WRITE_SIZE", {"mean_per_launch": 0})["mean_per_launch"] * 1024
     pmc["hbm_bytes_per_launch"] = fetch + write
     pmc["_correction"] = "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reads 1/2 on gfx950)"
-    json.dump({"hbm_bytes_per_launch": fetch + write, "source": tag + "_pmc.json"},
+    bytes_per_launch = None
+    bl = os.path.join(src, "bench_under_trace.log")
+    if os.path.exists(bl):
+        for l in open(bl, errors="replace"):
+            if l.startswith("{"):
+                bytes_per_launch = json.loads(l)["roofline"]["bytes_per_launch"]
+    # bench.py quotes this figure only for the workload (and launch size) it was taken on
+    json.dump({"hbm_bytes_per_launch": fetch + write, "source": tag + "_pmc.json", "workload": workload,
+               "bytes_per_launch": bytes_per_launch},
               open(os.path.join(out, "traffic_%s.json" % kname), "w"))
 json.dump(pmc, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
 for name in ("bench_under_trace.log",):

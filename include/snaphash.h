@@ -68,7 +68,9 @@ typedef struct snaphash_ctx snaphash_ctx;
 enum { /* snaphash_config.flags */
     SNAPHASH_FLAG_CHECK_GATHER = 1, /* several devices: also copy every device's digest slab to the host and
                                        require the RCCL-gathered vector to equal it (the collective's parity check) */
-    SNAPHASH_FLAG_NO_RCCL = 2       /* several devices: gather by per-device copies only */
+    SNAPHASH_FLAG_NO_RCCL = 2,      /* several devices: gather by per-device copies only */
+    SNAPHASH_FLAG_FORCE_GATHER = 4  /* run the gather (RCCL with one rank) even on a single-device ctx: lets a
+                                       1-GPU box exercise the collective path */
 };
 
 typedef struct snaphash_config {

@@ -30,7 +30,7 @@ EXPORTS = [
     "snaphash_batch_begin", "snaphash_batch_append", "snaphash_batch_end", "snaphash_batch_finish", "snaphash_batch_abort",
     "snaphash_tar_create", "snaphash_gzip_buffer", "snaphash_get_targz_stats",
 ]
-FLAG_CHECK_GATHER, FLAG_NO_RCCL = 1, 2
+FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER = 1, 2, 4
 
 
 class Config(ctypes.Structure):

@@ -556,7 +556,7 @@ int gather_digest_slabs(snaphash_ctx* x, const std::vector<size_t>& cnt, size_t 
             }
             x->gather_cap = kmax;
         }
-        for (size_t d = 0; d < nd; ++d) { // the slab every rank contributes is kmax rows: make sure it exists
+        for (size_t d = 0; d < nd; ++d) { // already sized by the caller before hashing (a growth here would drop the digests)
             DevCtx* c = x->dev[d].get();
             HIP_TRY(c, hipSetDevice(c->device));
             int rc = ensure_state(c, kmax, true);
@@ -697,6 +697,8 @@ void begin_top(snaphash_ctx* x)
     for (auto& d : x->dev) { begin_call(d.get()); d->t_call0 = 0; }
 }
 
+bool keep_on_device_planned(const snaphash_ctx* x, size_t nd) { return nd > 1 || (x->flags & SNAPHASH_FLAG_FORCE_GATHER); }
+
 int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests, int32_t* status)
 {
     const size_t n = src.size();
@@ -721,9 +723,19 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
         for (size_t k = 0; k < gidx.size(); ++k) member[shard[k]].push_back(gidx[k]);
     }
 
+    if (keep_on_device_planned(x, nd)) { // the slab every device contributes to the gather is kmax rows: size it BEFORE hashing
+        size_t kmax = 1;
+        for (size_t d = 0; d < nd; ++d) kmax = std::max(kmax, member[d].size());
+        for (size_t d = 0; d < nd; ++d) {
+            DevCtx* c = x->dev[d].get();
+            HIP_TRY(c, hipSetDevice(c->device));
+            const int rc = ensure_state(c, kmax, true);
+            if (rc) return lift(x, c, rc);
+        }
+    }
     struct DevJob { std::vector<Source> sub; std::vector<uint8_t> dig; int rc = 0, err_no = 0; int64_t err_src = -1; };
     std::vector<DevJob> job(nd);
-    const bool keep_on_device = nd > 1;
+    const bool keep_on_device = nd > 1 || (x->flags & SNAPHASH_FLAG_FORCE_GATHER); // digests stay in HBM for the gather
     auto run_dev = [&](size_t d) {
         DevJob& J = job[d];
         J.sub.reserve(member[d].size());
@@ -801,7 +813,7 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
         return bad_rc;
     }
 
-    if (nd == 1) {
+    if (!keep_on_device) {
         for (size_t k = 0; k < member[0].size(); ++k) memcpy(digests + 64 * (size_t)member[0][k], job[0].dig.data() + 64 * k, 64);
     } else {
         std::vector<size_t> cnt(nd);
@@ -1432,22 +1444,25 @@ void snaphash_batch_abort(snaphash_batch* b)
 
 namespace {
 
+// Chunk tables come in two halves (pinned host + device), so that the table of batch k+1 can be built
+// and uploaded while the kernel of batch k still reads its own.
 int ensure_chunks(DevCtx* c, size_t n)
 {
     if (n <= c->chunks_cap) return SNAPHASH_OK;
     const size_t want = std::max<size_t>(n, 4096);
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // nothing may still read the old tables
     if (c->h_chunks) (void)hipHostFree(c->h_chunks);
     if (c->d_chunks) (void)hipFree(c->d_chunks);
     c->h_chunks = nullptr; c->d_chunks = nullptr; c->chunks_cap = 0;
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_chunks, want * sizeof(CmpChunk), hipHostMallocDefault));
-    HIP_TRY(c, hipMalloc((void**)&c->d_chunks, want * sizeof(CmpChunk)));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_chunks, 2 * want * sizeof(CmpChunk), hipHostMallocDefault));
+    HIP_TRY(c, hipMalloc((void**)&c->d_chunks, 2 * want * sizeof(CmpChunk)));
     c->chunks_cap = want;
     return SNAPHASH_OK;
 }
 
 // Ranges (device addresses) -> chunk table -> kernel.  d_equal must hold one byte per pair.
 int launch_compare_ranges(DevCtx* c, const std::vector<uint64_t>& a, const std::vector<uint64_t>& b,
-                          const std::vector<uint64_t>& lens, uint8_t* d_equal)
+                          const std::vector<uint64_t>& lens, uint8_t* d_equal, int half = 0)
 {
     const size_t n = lens.size();
     size_t nchunks = 0;
@@ -1455,21 +1470,23 @@ int launch_compare_ranges(DevCtx* c, const std::vector<uint64_t>& a, const std::
     if (nchunks > 0xffffffffull) return fail(c, SNAPHASH_EINVAL, "too many comparison chunks");
     int rc = ensure_chunks(c, nchunks);
     if (rc) return rc;
+    CmpChunk* h_tab = c->h_chunks + (size_t)half * c->chunks_cap;
+    CmpChunk* d_tab = c->d_chunks + (size_t)half * c->chunks_cap;
     size_t k = 0;
     for (size_t i = 0; i < n; ++i)
         for (uint64_t off = 0; off < lens[i]; off += kCmpChunk) {
-            CmpChunk& ch = c->h_chunks[k++];
+            CmpChunk& ch = h_tab[k++];
             ch.a = a[i] + off;
             ch.b = b[i] + off;
             ch.nbytes = (uint32_t)std::min<uint64_t>(kCmpChunk, lens[i] - off);
             ch.pair = (uint32_t)i;
         }
     HIP_TRY(c, hipMemsetAsync(d_equal, 1, n, c->stream)); // equal until a chunk says otherwise
-    HIP_TRY(c, hipMemcpyAsync(c->d_chunks, c->h_chunks, nchunks * sizeof(CmpChunk), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_tab, h_tab, nchunks * sizeof(CmpChunk), hipMemcpyHostToDevice, c->stream));
     EventPair* ev = next_events(c, 0);
     if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
     HIP_TRY(c, hipEventRecord(ev->a, c->stream));
-    hipError_t e = launch_compare(c->d_chunks, (uint32_t)nchunks, d_equal, c->stream);
+    hipError_t e = launch_compare(d_tab, (uint32_t)nchunks, d_equal, c->stream);
     if (e != hipSuccess) return fail(c, SNAPHASH_EDEVICE, std::string("compare launch: ") + hipGetErrorString(e));
     HIP_TRY(c, hipEventRecord(ev->b, c->stream));
     c->stats.launches++;
@@ -1515,76 +1532,130 @@ int files_equal_impl(DevCtx* c, const char* const* a, const char* const* b, size
     int rc = ensure_slots(c);
     if (rc) return rc;
     for (const CmpPair& p : todo) equal[p.idx] = 1; // AND-ed down batch by batch
-    const uint64_t S = c->staging;
-    size_t first = 0;
-    while (first < todo.size()) {
-        // pack segments of consecutive pairs into the two staging buffers (A side: slot 0, B side: slot 1)
-        struct Seg { size_t t; uint64_t at, off, n; };
+    // Two halves of the staging buffers (A side: slot 0, B side: slot 1) alternate: the files of batch k+1
+    // are read and copied while the compare kernel of batch k runs; a batch's verdicts are collected when
+    // its half is needed again.
+    const uint64_t H = (c->staging / 2) & ~(uint64_t)(kAlign - 1);
+    struct Seg { size_t t; uint64_t at, off, n; };
+    struct Half {
         std::vector<Seg> segs;
+        std::vector<uint8_t> ok;
+        uint8_t* h_res = nullptr; // pinned
+        uint8_t* d_eq = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr, copied = nullptr;
+        bool busy = false;
+    } hf[2];
+    auto retire = [&](Half& h) -> int {
+        if (!h.busy) return SNAPHASH_OK;
+        HIP_TRY(c, hipEventSynchronize(h.done));
+        for (size_t i = 0; i < h.segs.size(); ++i)
+            if (!h.ok[i] || !h.h_res[i]) equal[todo[h.segs[i].t].idx] = 0;
+        h.busy = false;
+        return SNAPHASH_OK;
+    };
+    auto cleanup = [&]() {
+        for (Half& h : hf) {
+            if (h.h_res) (void)hipHostFree(h.h_res);
+            if (h.d_eq) (void)hipFree(h.d_eq);
+            if (h.done) (void)hipEventDestroy(h.done);
+            if (h.copied) (void)hipEventDestroy(h.copied);
+        }
+    };
+    size_t first = 0;
+    unsigned batch = 0;
+    rc = SNAPHASH_OK;
+    while (first < todo.size() && !rc) {
+        Half& h = hf[batch & 1];
+        const uint64_t base = (uint64_t)(batch & 1) * H;
+        rc = retire(h);
+        if (rc) break;
+        h.segs.clear();
         uint64_t used = 0;
         size_t t = first;
         while (t < todo.size()) {
             const uint64_t at = (used + kAlign - 1) & ~(uint64_t)(kAlign - 1);
-            if (at >= S) break;
-            const uint64_t take = std::min<uint64_t>(todo[t].len - todo[t].done, (S - at) & ~(uint64_t)15);
+            if (at >= H) break;
+            const uint64_t take = std::min<uint64_t>(todo[t].len - todo[t].done, (H - at) & ~(uint64_t)15);
             if (take == 0) break;
-            segs.push_back(Seg{t, at, todo[t].done, take});
+            h.segs.push_back(Seg{t, base + at, todo[t].done, take});
             used = at + take;
             todo[t].done += take;
-            if (todo[t].done < todo[t].len) break; // buffer full mid-file: the rest goes in the next batch
+            if (todo[t].done < todo[t].len) break; // half full mid-file: the rest goes in the next batch
             ++t;
         }
-        std::vector<uint8_t> ok(segs.size(), 1);
+        h.ok.assign(h.segs.size(), 1);
         {
             std::atomic<size_t> next{0};
             auto worker = [&]() {
                 for (;;) {
                     const size_t i = next.fetch_add(1);
-                    if (i >= segs.size()) return;
-                    const Seg& g = segs[i];
+                    if (i >= h.segs.size()) return;
+                    const Seg& g = h.segs[i];
                     const CmpPair& p = todo[g.t];
                     if (!read_exact(a[p.idx], g.off, g.n, c->slot[0].h_buf + g.at) ||
                         !read_exact(b[p.idx], g.off, g.n, c->slot[1].h_buf + g.at))
-                        ok[i] = 0;
+                        h.ok[i] = 0;
                 }
             };
             const unsigned T = (unsigned)std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
-                                                          std::max<size_t>(1, segs.size() / 2));
+                                                          std::max<size_t>(1, h.segs.size() / 2));
             std::vector<std::thread> th;
             for (unsigned k = 1; k < T; ++k) th.emplace_back(worker);
             worker();
             for (auto& x : th) x.join();
         }
-        if (segs.size() > c->equal_cap) {
-            if (c->d_equal) (void)hipFree(c->d_equal);
-            c->d_equal = nullptr; c->equal_cap = 0;
-            HIP_TRY(c, hipMalloc((void**)&c->d_equal, std::max<size_t>(segs.size(), 4096)));
-            c->equal_cap = std::max<size_t>(segs.size(), 4096);
+        if (h.segs.size() > h.cap) {
+            if (h.h_res) (void)hipHostFree(h.h_res);
+            if (h.d_eq) (void)hipFree(h.d_eq);
+            h.h_res = nullptr; h.d_eq = nullptr;
+            h.cap = std::max<size_t>(h.segs.size(), 4096);
+            if (hipMalloc((void**)&h.d_eq, h.cap) != hipSuccess || hipHostMalloc((void**)&h.h_res, h.cap, hipHostMallocDefault) != hipSuccess) {
+                rc = fail(c, SNAPHASH_ENOMEM, "allocation of the verdict buffers failed");
+                break;
+            }
+        }
+        if (!h.done && (hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&h.copied, hipEventDisableTiming) != hipSuccess)) {
+            rc = fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
+            break;
         }
         EventPair* ev = next_events(c, 1);
-        if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
-        HIP_TRY(c, hipEventRecord(ev->a, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->slot[0].d_buf, c->slot[0].h_buf, used, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->slot[1].d_buf, c->slot[1].h_buf, used, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipEventRecord(ev->b, c->stream));
-        std::vector<uint64_t> va(segs.size()), vb(segs.size()), vl(segs.size());
-        for (size_t i = 0; i < segs.size(); ++i) {
-            va[i] = (uint64_t)(uintptr_t)(c->slot[0].d_buf + segs[i].at);
-            vb[i] = (uint64_t)(uintptr_t)(c->slot[1].d_buf + segs[i].at);
-            vl[i] = segs[i].n;
+        if (!ev) { rc = fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed"); break; }
+        if (hipEventRecord(ev->a, c->copy_stream) != hipSuccess ||
+            hipMemcpyAsync(c->slot[0].d_buf + base, c->slot[0].h_buf + base, used, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+            hipMemcpyAsync(c->slot[1].d_buf + base, c->slot[1].h_buf + base, used, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+            hipEventRecord(ev->b, c->copy_stream) != hipSuccess || hipEventRecord(h.copied, c->copy_stream) != hipSuccess ||
+            hipStreamWaitEvent(c->stream, h.copied, 0) != hipSuccess) {
+            rc = fail(c, SNAPHASH_EDEVICE, "H2D of a comparison batch failed");
+            break;
         }
-        rc = launch_compare_ranges(c, va, vb, vl, c->d_equal);
-        if (rc) return rc;
-        std::vector<uint8_t> res(segs.size());
-        HIP_TRY(c, hipMemcpyAsync(res.data(), c->d_equal, segs.size(), hipMemcpyDeviceToHost, c->stream));
-        rc = sync_ctx(c);
-        if (rc) return rc;
-        for (size_t i = 0; i < segs.size(); ++i)
-            if (!ok[i] || !res[i]) equal[todo[segs[i].t].idx] = 0;
+        std::vector<uint64_t> va(h.segs.size()), vb(h.segs.size()), vl(h.segs.size());
+        for (size_t i = 0; i < h.segs.size(); ++i) {
+            va[i] = (uint64_t)(uintptr_t)(c->slot[0].d_buf + h.segs[i].at);
+            vb[i] = (uint64_t)(uintptr_t)(c->slot[1].d_buf + h.segs[i].at);
+            vl[i] = h.segs[i].n;
+        }
+        rc = launch_compare_ranges(c, va, vb, vl, h.d_eq, (int)(batch & 1));
+        if (rc) break;
+        if (hipMemcpyAsync(h.h_res, h.d_eq, h.segs.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipEventRecord(h.done, c->stream) != hipSuccess) {
+            rc = fail(c, SNAPHASH_EDEVICE, "D2H of the verdicts failed");
+            break;
+        }
+        h.busy = true;
+        ++batch;
         first = t; // t is the first pair with bytes left
         while (first < todo.size() && todo[first].done >= todo[first].len) ++first;
     }
-    return SNAPHASH_OK;
+    for (Half& h : hf) {
+        const int r2 = retire(h);
+        if (!rc) rc = r2;
+    }
+    const int r3 = sync_ctx(c);
+    if (!rc) rc = r3;
+    cleanup();
+    return rc;
 }
 
 } // namespace

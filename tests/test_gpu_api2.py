@@ -65,6 +65,20 @@ def test_all_visible_devices_and_rccl_gather(built_lib, oracle):
     assert got == [oracle.sha512(b) for b in bufs]
 
 
+def test_rccl_gather_path_with_one_rank(built_lib, oracle):
+    """FLAG_FORCE_GATHER: the digests stay in HBM and go through the library's single-process RCCL path
+    (dlopen, ncclCommInitAll, grouped ncclAllGather, D2H of the gathered slab) with one rank, checked against
+    the device's own copy -- the same code an 8-GPU ctx runs, on the one GPU this box has."""
+    from snappy_amd import Context, _lib
+    bufs = [os.urandom(int(n)) for n in _ragged_sizes(200, 26, 1 << 15)]
+    with Context(flags=_lib.FLAG_FORCE_GATHER | _lib.FLAG_CHECK_GATHER) as c:
+        got = c.sha512_buffers(bufs)
+        ex = c.stats_ex()
+        assert ex["gather_kind"] == 1 and ex["gather_checked"] == 1, ex
+        got2 = c.sha512_buffers(bufs[:17])  # a second call reuses the communicator
+    assert got == [oracle.sha512(b) for b in bufs] and got2 == got[:17]
+
+
 def test_streaming_batch_random_chunkings_vs_oracle(built_lib, oracle):
     """Row f2: the bytes of many files fed chunk by chunk, hash.Hash-style, sequentially per file (the
     tar producer's order) and interleaved across open files; every chunking gives the oracle's digests."""

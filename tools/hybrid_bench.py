@@ -65,6 +65,19 @@ head = int(np.argmax(sizes))
 assert d0[64 * head:64 * head + 64] == hashlib.sha512(host[int(off[head]):int(off[head]) + int(sizes[head])].tobytes()).digest()
 del host
 
+# config 3 scaled to host memory: 100 x 256 MiB from host buffers
+sizes3 = np.full(100, 256 << 20, dtype=np.uint64)
+host, off = host_tree(sizes3)
+total = int(sizes3.sum())
+(b0, d0) = run_buffers(host, off, sizes3)
+print("C3 scaled (100 x 256 MiB = 25 GiB), host buffers -> digests, GPU only: %.2f s = %.2f GiB/s" % (b0[0], total / 2**30 / b0[0]), flush=True)
+(b1, d1) = run_buffers(host, off, sizes3, host_threads=16)
+ex = b1[1]
+print("C3 scaled, hybrid host_threads=16: %.2f s = %.2f GiB/s; host: %d streams / %.1f GiB (busiest thread %.0f ms), GPU: %.1f GiB; digests identical: %s" % (
+    b1[0], total / 2**30 / b1[0], ex["host_streams"], ex["host_bytes"] / 2**30, ex["host_ms"], ex["gpu_bytes"] / 2**30, d0 == d1), flush=True)
+assert d0 == d1
+del host
+
 # a package whose data.tar.gz is as large as its tree (build.go:222 hashes it as ONE stream)
 base = "/dev/shm" if os.path.isdir("/dev/shm") else None
 tmp = tempfile.mkdtemp(prefix="snaphash_hyb_", dir=base)

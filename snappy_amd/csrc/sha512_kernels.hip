@@ -266,34 +266,30 @@ __device__ __forceinline__ void pair_round_wave(SplitShared& sh, uint32_t rw, ui
         const uint32_t addr =
             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(const void*)&sh.kw[ring][sl * kKwRow];
         ring = (ring == 2u) ? 0u : ring + 1u;
-        uint32_t x0l = lo32(Hx[0]), x0h = hi32(Hx[0]), x1l = lo32(Hx[1]), x1h = hi32(Hx[1]);
-        uint32_t x2l = lo32(Hx[2]), x2h = hi32(Hx[2]), x3l = lo32(Hx[3]), x3h = hi32(Hx[3]);
         uint32_t loop_counter; // scratch SGPR of the generated block
+        // the chaining words are updated in place: 80 rounds + the feed-forward add, all inside the generated block
         asm volatile(SNAPHASH_PAIR_ROUNDS_ASM
-                     : "+v"(x0l), "+v"(x0h), "+v"(x1l), "+v"(x1h), "+v"(x2l), "+v"(x2h), "+v"(x3l), "+v"(x3h),
-                       "=&s"(loop_counter)
+                     : "+v"(Hx[0]), "+v"(Hx[1]), "+v"(Hx[2]), "+v"(Hx[3]), "=&s"(loop_counter)
                      : "v"(c1), "v"(c2), "v"(c3), "v"(mb), "v"(addr)
                      : SNAPHASH_PAIR_CLOBBERS, "memory");
-        if (b < nblk) {
-            Hx[0] += mk64(x0l, x0h); Hx[1] += mk64(x1l, x1h);
-            Hx[2] += mk64(x2l, x2h); Hx[3] += mk64(x3l, x3h);
-        }
-    }
-    if (have) {
-        if (fin) {
-            uint4* o = reinterpret_cast<uint4*>(digests + (uint64_t)jb.idx * 64 + half * 8);
+        // A lane stores its result in the block-time its stream ends and rides along afterwards with a
+        // chaining value nobody reads: no per-block select (8 v_cndmask at ~19 cycles each for a lone wave).
+        if (b + 1u == nblk) {
+            if (fin) {
+                uint4* o = reinterpret_cast<uint4*>(digests + (uint64_t)jb.idx * 64 + half * 8);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                uint4 v;
-                v.x = __builtin_bswap32(hi32(Hx[2 * k]));
-                v.y = __builtin_bswap32(lo32(Hx[2 * k]));
-                v.z = __builtin_bswap32(hi32(Hx[2 * k + 1]));
-                v.w = __builtin_bswap32(lo32(Hx[2 * k + 1]));
-                o[k] = v;
+                for (int k = 0; k < 2; ++k) {
+                    uint4 v;
+                    v.x = __builtin_bswap32(hi32(Hx[2 * k]));
+                    v.y = __builtin_bswap32(lo32(Hx[2 * k]));
+                    v.z = __builtin_bswap32(hi32(Hx[2 * k + 1]));
+                    v.w = __builtin_bswap32(lo32(Hx[2 * k + 1]));
+                    o[k] = v;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) state[(uint64_t)jb.idx * 8 + half + k] = Hx[k];
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) state[(uint64_t)jb.idx * 8 + half + k] = Hx[k];
         }
     }
 }

@@ -99,7 +99,8 @@ def test_generated_inc_is_current():
         L = gp.LOOP_ROUNDS  # body: L rounds of 19 VALU, L/2 (ds_read2_b64 + s_waitcnt); + loop control
         assert n == 2 + 2 + L * 19 + L + 1 + 3 + 1
     else:
-        assert n == 2 + 80 * 19 + 39 + 40  # per round 19 VALU; per two rounds one ds_read2_b64 and one s_waitcnt
+        # per round 19 VALU; per eight rounds four ds_read2_b64, one s_waitcnt and one s_nop 0 (keeps the stream 8-byte aligned)
+        assert n == 1 + 80 * 19 + 40 + 10 + 10
 
 
 def test_dpp_hazard_distance():

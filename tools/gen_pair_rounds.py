@@ -30,7 +30,7 @@ import os
 import numpy as np
 
 M32 = 0xFFFFFFFF
-BASE = 64  # first physical VGPR of the block; the kernel lists v64..v97 as clobbers
+BASE = 64  # first physical VGPR of the block; the kernel lists v64..v157 as clobbers
 
 # ---- register map -----------------------------------------------------------------
 REG = {}
@@ -42,25 +42,41 @@ def _alloc():
     for name in ("C1", "C2", "C3", "MB", "ADDR", "spare"):  # per-lane constants
         REG[name] = n
         n += 1
-    for name in ("T", "U", "S", "M", "BF", "VV", "TT", "V2", "KW0", "KW1", "KW2", "KW3"):  # aligned pairs
+    for name in ["T", "U", "S", "M", "BF", "VV", "TT", "V2"] + ["KW%d" % k for k in range(32)]:  # aligned pairs
         REG[name + "l"], REG[name + "h"] = n, n + 1
         n += 2
     return n
 LAST = _alloc() - 1
-assert BASE % 2 == 0 and LAST == 101
+assert BASE % 2 == 0 and LAST == 157
 
 IN_ORDER = ["R0l", "R0h", "R1l", "R1h", "R2l", "R2h", "R3l", "R3h", "C1", "C2", "C3", "MB", "ADDR"]
 A_BANKS, B_BANKS = 0x5, 0xA
 
 
+# Code placement experiment (MI355X_MICROARCH.md, "Code-placement sensitivity of hand-written streams"): every
+# instruction of the block is 8 bytes except s_waitcnt (4), so the stream's phase mod 8 flips at every wait.
+#   "none": as is;  "nop": an s_nop 0 behind every in-round s_waitcnt (phase constant, one more issue slot per
+#   two rounds);  "p2": .p2align 3 in front of the block;  "both".
+ALIGN = os.environ.get("SNAPHASH_PAIR_ALIGN", "w8")
+# "w4" (shipped): K+W arrives four rounds per wait -- two ds_read2_b64 back to back every four rounds, ONE
+# s_waitcnt + ONE s_nop 0 (together 8 bytes) in front of the first use: the instruction stream stays at phase 0
+# mod 8 throughout at the same number of issue slots as the two-round scheme.  Measured on C2 (10 001 x 1 MiB):
+# none 26.9 ms, nop 25.3 ms, w4 see profiles/r02_pair_alignment.txt.
+SCHEME = "w4" if ALIGN in ("w4", "w8", "w16") else "w2"
+WN = {"w8": 8, "w16": 16}.get(ALIGN, 4)  # rounds of K+W per wait in the aligned scheme (2 * WN register pairs)
+_active_scheme = [SCHEME]  # the hardware-loop forms (experiments) always use the two-round scheme
 ORDER = os.environ.get("SNAPHASH_PAIR_ORDER", "interleave")  # "interleave" (shipped: VOP2 between the VOP3s, 30.06 vs 30.20 ms on C2) or "plain"
 
 
 def one_round(e, i, kw_prefetch, wait):
-    """Appends round i (register roles depend on i mod 4 only)."""
+    """Appends round i (register roles depend on i mod 4 only).  kw_prefetch: None, a K+W word index (two-round
+    scheme: one ds_read2_b64 every two rounds) or a list of (register, word index) reads (four-round scheme)."""
     x = ["R%d" % ((k - i) % 4) for k in range(4)]  # x0..x3 of this round
-    kw = "KW%d" % (i & 3)
-    if kw_prefetch is not None:
+    kw = "KW%d" % ((i % (2 * WN)) if _active_scheme[0] == "w4" else (i & 3))
+    if isinstance(kw_prefetch, list):
+        for reg, word in kw_prefetch:
+            e(("ds_read2_b64", reg, "ADDR", word))
+    elif kw_prefetch is not None:
         e(("ds_read2_b64", "KW%d" % ((i + 2) & 3), "ADDR", kw_prefetch))
     if ORDER.startswith("seed:"):
         # experiment: a random topological order of the round's 15 non-DPP instructions (the four
@@ -101,9 +117,9 @@ def one_round(e, i, kw_prefetch, wait):
         for k in done:
             if body[k][0] == "add64" and body[k][1] == "TT" and wait is not None:
                 e(("waitcnt", wait))
+                if ALIGN in ("nop", "both", "w4", "w8", "w16"):
+                    e(("nop",))
             e(body[k])
-        if wait is not None and not any(body[k][1] == "TT" for k in done):
-            e(("waitcnt", wait))
         e(("add_co_dpp", x[3] + "l", x[3] + "l", "V2l", A_BANKS))
         e(("addc_co_dpp", x[3] + "h", x[3] + "h", "V2h", A_BANKS))
         e(("add_co_dpp", x[3] + "l", "V2l", "VVl", B_BANKS))
@@ -122,6 +138,8 @@ def one_round(e, i, kw_prefetch, wait):
         e(("bfi", "BFh", "Mh", x[1] + "h", x[2] + "h"))
         if wait is not None:
             e(("waitcnt", wait))
+            if ALIGN in ("nop", "both", "w4", "w8", "w16"):
+                e(("nop",))
         e(("add64", "TT", x[3], kw))
         e(("alignbit", "Sl", "Th", "Tl", "C3"))
         e(("alignbit", "Sh", "Tl", "Th", "C3"))
@@ -149,6 +167,8 @@ def one_round(e, i, kw_prefetch, wait):
     e(("add64", "VV", "S", "BF"))            # A: Sigma1+Ch ; B: T2 = Sigma0+Maj
     if wait is not None:
         e(("waitcnt", wait))
+        if ALIGN in ("nop", "both", "w4", "w8", "w16"):
+            e(("nop",))
     e(("add64", "TT", x[3], kw))             # A: h + (K+W) ; B: unused
     e(("add64", "V2", "VV", "TT"))           # A: T1 ; B: unused
     # x3 <- new chain value (x0 of the next round)
@@ -167,6 +187,20 @@ def build(rounds=80, loop_rounds=0):
     iteration and the last iteration prefetches two words past the row (never used)."""
     ins = []
     e = ins.append
+    _active_scheme[0] = SCHEME if not loop_rounds else "w2"
+    if SCHEME == "w4" and not loop_rounds:
+        e(("waitcnt", 0))
+        for k in range(0, WN, 2):
+            e(("ds_read2_b64", "KW%d" % k, "ADDR", k))
+        for i in range(rounds):
+            if i % WN == 0:
+                more = i + WN < rounds
+                nxt = ((i // WN + 1) & 1) * WN
+                pre = [("KW%d" % (nxt + k), i + WN + k) for k in range(0, WN, 2)] if more else []
+                one_round(e, i, pre, WN // 2 if more else 0)
+            else:
+                one_round(e, i, None, None)
+        return ins
     e(("waitcnt", 0))
     e(("ds_read2_b64", "KW0", "ADDR", 0))
     if not loop_rounds:
@@ -198,6 +232,8 @@ def to_asm(ins):
         op = t[0]
         if op == "waitcnt":
             out.append("s_waitcnt lgkmcnt(%d)" % t[1])
+        elif op == "nop":
+            out.append("s_nop 0")
         elif op == "ds_read2_b64":  # two u64 at ADDR + 8*t[3] and ADDR + 8*(t[3]+1) into 4 consecutive VGPRs
             out.append("ds_read2_b64 v[%d:%d], %s offset0:%d offset1:%d" %
                        (REG[t[1] + "l"], REG[t[1] + "l"] + 3, v(t[2]), t[3], t[3] + 1))
@@ -239,22 +275,28 @@ LOOP_ROUNDS = 0  # rounds per hardware-loop iteration in the shipped block (0 = 
 def write_inc(path, loop_rounds=LOOP_ROUNDS):
     ins = build(loop_rounds=loop_rounds)
     body = to_asm(ins)
-    n_valu = sum(1 for t in ins if t[0] not in ("waitcnt", "ds_read2_b64"))
+    n_valu = sum(1 for t in ins if t[0] not in ("waitcnt", "ds_read2_b64", "nop"))
     lines = ["// GENERATED by tools/gen_pair_rounds.py -- do not edit.",
              "// One 128-byte block = 80 SHA-512 rounds on lane pairs; %d VALU + %d LDS reads." %
              (n_valu, sum(1 for t in ins if t[0] == "ds_read2_b64")),
-             "// Physical registers v%d..v%d (clobbered); operands %%0..%%7 = state halves (in/out)," % (BASE, LAST),
-             "// %8 = scratch SGPR (loop counter, output), %9..%11 = per-lane rotate amounts, %12 = role mask",
-             "// (B: ~0, A: 0), %13 = LDS byte address of the stream's K+W row.",
+             "// Physical registers v%d..v%d (clobbered).  Operands: %%0..%%3 = the four chaining words of this lane, 64-bit," % (BASE, LAST),
+             "// updated in place (chaining value + working variables: the feed-forward is done here), %4 = scratch",
+             "// SGPR, %5..%7 = per-lane rotate amounts, %8 = role mask (B: ~0, A: 0), %9 = LDS byte address of the",
+             "// stream's K+W row.",
              "#define SNAPHASH_PAIR_FIRST_VGPR %d" % BASE,
              "#define SNAPHASH_PAIR_LAST_VGPR %d" % LAST,
              "#define SNAPHASH_PAIR_ROUNDS_ASM \\"]
-    for k, name in enumerate(IN_ORDER):
-        lines.append('    "v_mov_b32 %s, %%%d\\n" \\' % (v(name), k if k < 8 else k + 1))
-    for s in body:
-        lines.append('    "%s\\n" \\' % s)
-    for k, name in enumerate(IN_ORDER[:8]):
-        lines.append('    "v_mov_b32 %%%d, %s\\n" \\' % (k, v(name)))
+    if ALIGN in ("p2", "both", "w4", "w8", "w16"):
+        lines.append('    ".p2align %s\\n" \\' % os.environ.get("SNAPHASH_PAIR_P2", "3"))
+    for k in range(4):      # working variables <- chaining value: 4 x v_mov_b64 (4 bytes each)
+        lines.append('    "v_mov_b64 %s, %%%d\\n" \\' % (vp("R%d" % k), k))
+    for k, name in enumerate(IN_ORDER[8:]):  # 5 x v_mov_b32: with the s_waitcnt that follows, 40 bytes
+        lines.append('    "v_mov_b32 %s, %%%d\\n" \\' % (v(name), 5 + k))
+    for s_ in body:
+        lines.append('    "%s\\n" \\' % s_)
+    assert build().__len__() and 80 % 4 == 0  # after 80 rounds the register roles are back where they started
+    for k in range(4):      # feed-forward: out = working + chaining value
+        lines.append('    "v_lshl_add_u64 %%%d, %s, 0, %%%d\\n" \\' % (k, vp("R%d" % k), k))
     lines.append('    ""')
     clob = ", ".join('"v%d"' % n for n in range(BASE, LAST + 1))
     lines.append("#define SNAPHASH_PAIR_CLOBBERS %s, \"vcc\", \"scc\"" % clob)
@@ -299,6 +341,8 @@ def simulate(ins, regs, lds):
             i += 1
     for t in seq:
         op = t[0]
+        if op == "nop":
+            continue
         if op == "waitcnt":
             while len(pending) > t[1]:
                 pending.pop(0)

@@ -59,8 +59,9 @@ enum { /* snaphash_config.kernel */
     SNAPHASH_KERNEL_WIDE = 1, /* one lane per file stream does rounds + schedule (many-stream regime) */
     SNAPHASH_KERNEL_SPLIT = 2, /* rounds on one wave, message schedule on helper waves, K+W through
                                   an LDS ring (stream-starved regime: fewer streams than lanes) */
-    SNAPHASH_KERNEL_PAIR = 3   /* SPLIT with every stream carried by a lane pair (e-chain / a-chain,
-                                  DPP exchange): fewest instructions on the critical wave */
+    SNAPHASH_KERNEL_PAIR = 3,  /* SPLIT with every stream carried by a lane pair (e-chain / a-chain,
+                                  DPP exchange) */
+    SNAPHASH_KERNEL_QUAD = 4   /* four lanes per stream (role x 32-bit half): fewest instructions on the critical wave */
 };
 
 typedef struct snaphash_ctx snaphash_ctx;

@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNAPHASH_LIB") or os.path.join(_HERE, "libsnaphash.so")
 
 OK, EINVAL, ENOMEM, EIO, EDEVICE, EMODE, ENAME, EPARSE, EMISMATCH = 0, -1, -2, -3, -4, -5, -6, -7, -8
-KERNEL_AUTO, KERNEL_WIDE, KERNEL_SPLIT, KERNEL_PAIR = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_WIDE, KERNEL_SPLIT, KERNEL_PAIR, KERNEL_QUAD = 0, 1, 2, 3, 4
 KERNEL_NAMES = {KERNEL_WIDE: "sha512_wide_kernel", KERNEL_SPLIT: "sha512_split_kernel<false>",
-                KERNEL_PAIR: "sha512_split_kernel<true>"}
+                KERNEL_PAIR: "sha512_split_kernel<true>", KERNEL_QUAD: "sha512_quad_kernel"}
 
 # every symbol include/snaphash.h declares
 EXPORTS = [

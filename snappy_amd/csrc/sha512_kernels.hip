@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "pair_rounds.inc"
+#include "quad_rounds.inc"
 #include "sha512_core.h"
 #include "sha512_kernels.h"
 
@@ -185,6 +186,7 @@ struct SplitShared {
     uint4 tile[2][64 * kTileRow];  // one staging tile per helper wave
     uint32_t maxblk;
     uint32_t pad_[3];
+    uint64_t zeros[kKwRow];        // QUAD: the a-chain lanes read their "K+W" here (they add d + 0)
 };
 
 __device__ __forceinline__ void load_kw16(uint64_t k[16], const uint64_t* __restrict__ row)
@@ -294,6 +296,68 @@ __device__ __forceinline__ void pair_round_wave(SplitShared& sh, uint32_t rw, ui
     }
 }
 
+// Helper wave hk (0: even blocks, 1: odd blocks) of a 64-stream workgroup: fetch the 128-byte blocks
+// (coalesced, staged in a wave-private LDS tile), byte-swap, pad, expand the message schedule and store
+// K[t]+W[t] into the ring; lane = stream.  Shared by the SPLIT, PAIR and QUAD kernels.
+__device__ __forceinline__ void split_helper_wave(SplitShared& sh, uint32_t hk, uint32_t lane, const Job& jb, uint32_t nblk,
+                                                  uint32_t steps)
+{
+    const uint64_t nbytes = jb.nbytes;
+    const uint32_t nfull = (uint32_t)(nbytes >> 7);
+    const uint32_t rem = (uint32_t)(nbytes & 127);
+    const uint64_t total = jb.total_prev + nbytes;
+    uint4* __restrict__ tile = sh.tile[hk];
+    const uint32_t piece = lane & 7u;
+    const uint8_t* tptr[8];
+    uint32_t tnp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = 8 * i + (int)(lane >> 3);
+        const uint64_t dd = shfl_u64(jb.data, t);
+        const uint64_t nb = shfl_u64(nbytes, t);
+        tptr[i] = reinterpret_cast<const uint8_t*>(dd) + piece * 16u;
+        tnp[i] = (uint32_t)((nb + 15u) >> 4);
+    }
+    uint4 pre[8]; // block hk, then hk+2, ... (prefetched two block-times ahead of its use)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t p = hk * 8u + piece;
+        pre[i] = make_uint4(0, 0, 0, 0);
+        if (p < tnp[i]) pre[i] = load_u4(tptr[i] + (uint64_t)hk * 128u);
+    }
+    uint64_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = 0;
+    for (uint32_t tau = 0; tau < steps; ++tau) {
+        __syncthreads();
+        if ((tau & 1u) == hk) {
+            // first half of block tau: stage, swap, pad, words 0..39
+            const uint32_t b = tau;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tile[(8 * i + (lane >> 3)) * kTileRow + piece] = pre[i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t p = (b + 2u) * 8u + piece;
+                pre[i] = make_uint4(0, 0, 0, 0);
+                if (p < tnp[i]) pre[i] = load_u4(tptr[i] + (uint64_t)(b + 2u) * 128u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint4 q = tile[lane * kTileRow + k];
+                w[2 * k] = be64(q.x, q.y);
+                w[2 * k + 1] = be64(q.z, q.w);
+            }
+            if (__any(b >= nfull && b < nblk)) apply_padding(w, b >= nfull, b - nfull, rem, total);
+            schedule_span<0, 40>(w, &sh.kw[b % 3u][lane * kKwRow]);
+        } else if (tau >= 1u) {
+            // second half of block tau-1: words 40..79
+            schedule_span<40, 80>(w, &sh.kw[(tau - 1u) % 3u][lane * kKwRow]);
+        }
+    }
+}
+
 template <bool PAIR>
 __global__ __launch_bounds__(PAIR ? 256 : 192) void sha512_split_kernel(const Job* __restrict__ jobs, uint32_t njobs,
                                                                         uint64_t* __restrict__ state,
@@ -312,12 +376,8 @@ __global__ __launch_bounds__(PAIR ? 256 : 192) void sha512_split_kernel(const Jo
     } else {
         jb.data = 0; jb.nbytes = 0; jb.total_prev = 0; jb.idx = 0; jb.flags = 0;
     }
-    const uint64_t nbytes = jb.nbytes;
-    const uint32_t nfull = (uint32_t)(nbytes >> 7);
-    const uint32_t rem = (uint32_t)(nbytes & 127);
     const bool fin = (jb.flags & kJobFinal) != 0;
-    const uint32_t nblk = have ? padded_blocks(nbytes, fin) : 0u;
-    const uint64_t total = jb.total_prev + nbytes;
+    const uint32_t nblk = have ? padded_blocks(jb.nbytes, fin) : 0u;
 
     if (threadIdx.x == 0) sh.maxblk = 0;
     __syncthreads();
@@ -375,58 +435,108 @@ __global__ __launch_bounds__(PAIR ? 256 : 192) void sha512_split_kernel(const Jo
         return;
     }
 
-    // ---------------- helper waves ----------------
-    const uint32_t hk = wave - kRoundWaves; // 0: even blocks, 1: odd blocks
-    uint4* __restrict__ tile = sh.tile[hk];
-    const uint32_t piece = lane & 7u;
-    const uint8_t* tptr[8];
-    uint32_t tnp[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int t = 8 * i + (int)(lane >> 3);
-        const uint64_t dd = shfl_u64(jb.data, t);
-        const uint64_t nb = shfl_u64(nbytes, t);
-        tptr[i] = reinterpret_cast<const uint8_t*>(dd) + piece * 16u;
-        tnp[i] = (uint32_t)((nb + 15u) >> 4);
+    split_helper_wave(sh, wave - kRoundWaves, lane, jb, nblk, steps);
+}
+
+// ---------------------------------------------------------------------------
+// QUAD kernel: as PAIR, with every stream on FOUR lanes of a round wave -- role (e-chain / a-chain) x
+// half (low / high 32 bits) -- so that rotations and bitwise functions are one instruction instead of
+// two; additions carry in (value, 0) register pairs and the carry crosses to the high lane once per
+// round (tools/gen_quad_rounds.py -> quad_rounds.inc, proven on the CPU lane simulator,
+// tests/test_quad_sim.py).  16 VALU + 1 LDS read per round instead of 19 + 0.5.  Four round waves of 16
+// streams and the two helper waves per 64-stream workgroup: the helpers share SIMDs with round waves,
+// which run at s_setprio 3 and are not slowed by them (profiles/r02_ubench_gfx950.txt, k_share).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void quad_round_wave(SplitShared& sh, uint32_t rw, uint32_t lane, const Job* __restrict__ jobs,
+                                                uint32_t njobs, uint32_t steps, uint64_t* __restrict__ state,
+                                                uint8_t* __restrict__ digests)
+{
+    const uint32_t j = lane & 7u;
+    const bool is_hi = (lane & 4u) != 0u, is_b = (lane & 8u) != 0u;
+    const uint32_t sl = 16u * rw + 4u * (lane >> 4) + (is_hi ? 7u - j : j); // stream within the workgroup
+    const uint32_t slot = blockIdx.x * 64u + sl;
+    const bool have = slot < njobs;
+    Job jb;
+    if (have) {
+        jb = jobs[slot];
+    } else {
+        jb.data = 0; jb.nbytes = 0; jb.total_prev = 0; jb.idx = 0; jb.flags = 0;
     }
-    uint4 pre[8]; // block hk, then hk+2, ... (prefetched two block-times ahead of its use)
+    const bool fin = (jb.flags & kJobFinal) != 0;
+    const uint32_t nblk = have ? padded_blocks(jb.nbytes, fin) : 0u;
+    const uint32_t word0 = is_b ? 0u : 4u; // B owns H[0..3] = a,b,c,d ; A owns H[4..7] = e,f,g,h
+    // this lane's half of its four chaining words, zero-extended: the (value, 0) pair format of the block
+    uint64_t h0, h1, h2, h3;
+    {
+        uint64_t hx[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t p = hk * 8u + piece;
-        pre[i] = make_uint4(0, 0, 0, 0);
-        if (p < tnp[i]) pre[i] = load_u4(tptr[i] + (uint64_t)hk * 128u);
+        for (int k = 0; k < 4; ++k) {
+            uint64_t full = IV512[word0 + k];
+            if (!(jb.flags & kJobFirst)) full = have ? state[(uint64_t)jb.idx * 8 + word0 + k] : 0;
+            hx[k] = is_hi ? (full >> 32) : (full & 0xffffffffull);
+        }
+        h0 = hx[0]; h1 = hx[1]; h2 = hx[2]; h3 = hx[3];
     }
-    uint64_t w[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) w[k] = 0;
+    const uint32_t c1 = is_b ? 6u : 4u, c2 = is_b ? 11u : 27u, c3 = is_b ? 28u : 14u;
+    const uint32_t mb = is_b ? 0xffffffffu : 0u;
+    const uint32_t zero = 0u;
+    uint32_t ring = 0;
+    __builtin_amdgcn_s_setprio(3);
     for (uint32_t tau = 0; tau < steps; ++tau) {
         __syncthreads();
-        if ((tau & 1u) == hk) {
-            // first half of block tau: stage, swap, pad, words 0..39
-            const uint32_t b = tau;
-            __builtin_amdgcn_wave_barrier();
+        if (tau < 2) continue;
+        const uint32_t b = tau - 2u;
+        const uint64_t* row = is_b ? sh.zeros : &sh.kw[ring][sl * kKwRow];
+        const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(const void*)row + (is_hi && !is_b ? 4u : 0u);
+        ring = (ring == 2u) ? 0u : ring + 1u;
+        asm volatile(SNAPHASH_QUAD_ROUNDS_ASM
+                     : SNAPHASH_QUAD_HP0(h0), SNAPHASH_QUAD_HP1(h1), SNAPHASH_QUAD_HP2(h2), SNAPHASH_QUAD_HP3(h3)
+                     : SNAPHASH_QUAD_C1(c1), SNAPHASH_QUAD_C2(c2), SNAPHASH_QUAD_C3(c3), SNAPHASH_QUAD_MB(mb),
+                       SNAPHASH_QUAD_ADDR(addr), SNAPHASH_QUAD_ZERO_INPUTS(zero)
+                     : SNAPHASH_QUAD_CLOBBERS, "memory");
+        if (b + 1u == nblk) { // the stream ends in this block-time: store now, ride along afterwards
+            const uint32_t v[4] = {(uint32_t)h0, (uint32_t)h1, (uint32_t)h2, (uint32_t)h3};
+            if (fin) {
+                // big-endian 64-bit words: the high half comes first
+                uint32_t* o = reinterpret_cast<uint32_t*>(digests + (uint64_t)jb.idx * 64 + word0 * 8u + (is_hi ? 0u : 4u));
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tile[(8 * i + (lane >> 3)) * kTileRow + piece] = pre[i];
-            __builtin_amdgcn_wave_barrier();
+                for (int k = 0; k < 4; ++k) o[2 * k] = __builtin_bswap32(v[k]);
+            } else {
+                uint32_t* o = reinterpret_cast<uint32_t*>(state + (uint64_t)jb.idx * 8 + word0) + (is_hi ? 1 : 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t p = (b + 2u) * 8u + piece;
-                pre[i] = make_uint4(0, 0, 0, 0);
-                if (p < tnp[i]) pre[i] = load_u4(tptr[i] + (uint64_t)(b + 2u) * 128u);
+                for (int k = 0; k < 4; ++k) o[2 * k] = v[k];
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint4 q = tile[lane * kTileRow + k];
-                w[2 * k] = be64(q.x, q.y);
-                w[2 * k + 1] = be64(q.z, q.w);
-            }
-            if (__any(b >= nfull && b < nblk)) apply_padding(w, b >= nfull, b - nfull, rem, total);
-            schedule_span<0, 40>(w, &sh.kw[b % 3u][lane * kKwRow]);
-        } else if (tau >= 1u) {
-            // second half of block tau-1: words 40..79
-            schedule_span<40, 80>(w, &sh.kw[(tau - 1u) % 3u][lane * kKwRow]);
         }
     }
+}
+
+__global__ __launch_bounds__(384) void sha512_quad_kernel(const Job* __restrict__ jobs, uint32_t njobs,
+                                                          uint64_t* __restrict__ state, uint8_t* __restrict__ digests)
+{
+    __shared__ SplitShared sh;
+    constexpr uint32_t kRoundWaves = 4u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t slot = blockIdx.x * 64u + lane;
+    const bool have = slot < njobs;
+    Job jb;
+    if (have) {
+        jb = jobs[slot];
+    } else {
+        jb.data = 0; jb.nbytes = 0; jb.total_prev = 0; jb.idx = 0; jb.flags = 0;
+    }
+    const uint32_t nblk = have ? padded_blocks(jb.nbytes, (jb.flags & kJobFinal) != 0) : 0u;
+    if (threadIdx.x == 0) sh.maxblk = 0;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kKwRow; i += 384u) sh.zeros[i] = 0;
+    __syncthreads();
+    if (wave == kRoundWaves) atomicMax(&sh.maxblk, nblk); // first helper wave: lane = stream
+    __syncthreads();
+    const uint32_t steps = sh.maxblk + 2u; // every wave runs exactly `steps` barriers below
+    if (wave < kRoundWaves) {
+        quad_round_wave(sh, wave, lane, jobs, njobs, steps, state, digests);
+        return;
+    }
+    split_helper_wave(sh, wave - kRoundWaves, lane, jb, nblk, steps);
 }
 
 // ---------------------------------------------------------------------------
@@ -543,6 +653,14 @@ hipError_t launch_pair(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uin
     if (njobs == 0) return hipSuccess;
     const uint32_t grid = (njobs + 63u) / 64u;
     hipLaunchKernelGGL(sha512_split_kernel<true>, dim3(grid), dim3(256), 0, s, d_jobs, njobs, d_state, d_digests);
+    return hipGetLastError();
+}
+
+hipError_t launch_quad(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s)
+{
+    if (njobs == 0) return hipSuccess;
+    const uint32_t grid = (njobs + 63u) / 64u;
+    hipLaunchKernelGGL(sha512_quad_kernel, dim3(grid), dim3(384), 0, s, d_jobs, njobs, d_state, d_digests);
     return hipGetLastError();
 }
 

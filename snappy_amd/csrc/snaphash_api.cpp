@@ -256,6 +256,7 @@ uint64_t job_blocks(const Job& j) { return (j.nbytes >> 7) + 1; }
 
 hipError_t launch_kernel(uint32_t k, const Job* d_jobs, size_t n, DevCtx* c, uint8_t* d_digests)
 {
+    if (k == SNAPHASH_KERNEL_QUAD) return launch_quad(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
     if (k == SNAPHASH_KERNEL_PAIR) return launch_pair(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
     if (k == SNAPHASH_KERNEL_SPLIT) return launch_split(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
     return launch_wide(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
@@ -267,7 +268,7 @@ size_t plan_kernels(const DevCtx* c, const Job* h_jobs, size_t n, uint32_t* k_he
 {
     *k_tail = SNAPHASH_KERNEL_WIDE;
     if (c->kernel_pref == SNAPHASH_KERNEL_WIDE || c->kernel_pref == SNAPHASH_KERNEL_SPLIT ||
-        c->kernel_pref == SNAPHASH_KERNEL_PAIR) {
+        c->kernel_pref == SNAPHASH_KERNEL_PAIR || c->kernel_pref == SNAPHASH_KERNEL_QUAD) {
         *k_head = c->kernel_pref;
         return n;
     }

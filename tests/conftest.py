@@ -31,11 +31,12 @@ def built_lib():
     return _lib.lib()
 
 
-@pytest.fixture(scope="session", params=["wide", "split", "pair", "auto"])
+@pytest.fixture(scope="session", params=["wide", "split", "pair", "quad", "auto"])
 def ctx(built_lib, request):
     """A GPU context per kernel variant; only gpu-marked tests may request it."""
     from snappy_amd import Context, _lib
-    kern = {"wide": _lib.KERNEL_WIDE, "split": _lib.KERNEL_SPLIT, "pair": _lib.KERNEL_PAIR, "auto": _lib.KERNEL_AUTO}[request.param]
+    kern = {"wide": _lib.KERNEL_WIDE, "split": _lib.KERNEL_SPLIT, "pair": _lib.KERNEL_PAIR, "quad": _lib.KERNEL_QUAD,
+            "auto": _lib.KERNEL_AUTO}[request.param]
     c = Context(kernel=kern)
     yield c
     c.close()

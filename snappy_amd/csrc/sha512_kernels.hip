@@ -306,6 +306,11 @@ __device__ __forceinline__ void split_helper_wave(SplitShared& sh, uint32_t hk, 
     const uint32_t nfull = (uint32_t)(nbytes >> 7);
     const uint32_t rem = (uint32_t)(nbytes & 127);
     const uint64_t total = jb.total_prev + nbytes;
+#if defined(SNAPHASH_EXPERIMENT_IDLE_HELPERS) // timing experiment only (wrong digests): what do the round waves cost alone?
+    for (uint32_t tau = 0; tau < steps; ++tau) __syncthreads();
+    (void)nfull; (void)rem; (void)total; (void)hk; (void)lane;
+    return;
+#endif
     uint4* __restrict__ tile = sh.tile[hk];
     const uint32_t piece = lane & 7u;
     const uint8_t* tptr[8];

@@ -7,12 +7,12 @@
 // must return exactly the tar stream -- not the bytes Go's compressor would emit.
 //
 // Parallel axis: the stream is cut into 16 KiB chunks; one wave64 compresses one chunk on its
-// own (hash table in LDS, no back-references across chunks) into a fixed-Huffman block, ends
+// own (hash table in LDS, seeded with the previous chunk so that matches reach 32 KiB back) into a fixed-Huffman block, ends
 // it with an empty stored block so that the chunk's output is byte aligned (what zlib's
 // Z_SYNC_FLUSH does), and the chunk outputs are concatenated by a second kernel.  A chunk
 // that does not shrink is emitted as a stored block.  Per tile of 64 input positions
 // (lane = position): hash 4 bytes, look the candidate up, extend the match, a scalar greedy
-// parse over the wave's match mask, then every token-start lane encodes its own token and a
+// parse with one-byte lazy evaluation over the wave's match mask, then every token-start lane encodes its own token and a
 // prefix sum of the bit lengths places it in the LDS bit buffer.
 //
 // This kernel is integer/LDS work with data-dependent control flow: no MFMA.  Bound: each input
@@ -69,6 +69,17 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
     for (uint32_t i = lane; i < kTab / 2u; i += 64u) reinterpret_cast<uint32_t*>(tab)[i] = 0u;
     ob[lane] = (lane == 0u) ? 2u : 0u; // BFINAL=0, BTYPE=01 (fixed Huffman): bits 0,1,0 LSB first
     __builtin_amdgcn_wave_barrier();
+    // Window: the table is seeded with the previous chunk's positions (when this launch holds it), so a match may
+    // reach up to 32 KiB back across the chunk boundary -- the inflater does not care about block boundaries.
+    // Table entries are position + kDeflateChunk + 1 (0 = empty): previous-chunk positions are 1 .. kDeflateChunk.
+    if (c > 0u) {
+        const uint8_t* prev = src - kDeflateChunk;
+        for (uint32_t p = lane; p < kDeflateChunk; p += 64u) {
+            const uint32_t w = load32(prev + p);
+            tab[(w * 0x9E3779B1u) >> (32u - kHashBits)] = (uint16_t)(p + 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     uint32_t bitpos = 3u;      // bits of this chunk's stream so far (wave-uniform)
     uint32_t flushed = 0u;     // 32-bit words already stored to dst
     uint32_t skip_until = 0u;  // first position not covered by an earlier match
@@ -83,20 +94,20 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
         uint32_t cand = 0;
         if (canmatch) cand = tab[h];
         __builtin_amdgcn_wave_barrier();
-        if (canmatch) tab[h] = (uint16_t)(pos + 1u); // any lane may win the slot
+        if (canmatch) tab[h] = (uint16_t)(pos + kDeflateChunk + 1u); // lanes are served in order: the highest position stays
         __builtin_amdgcn_wave_barrier();
         uint32_t mlen = 0, dist = 0;
         if (canmatch && cand != 0u) {
-            const uint32_t cp = cand - 1u; // from an earlier tile: cp < p0 <= pos
+            const int32_t cp = (int32_t)cand - 1 - (int32_t)kDeflateChunk; // an earlier tile or the previous chunk (< 0)
             const uint32_t maxl = (len - pos < 258u) ? len - pos : 258u;
             uint32_t l = 0;
             while (l < maxl) {
-                const uint32_t x = load32(src + pos + l) ^ load32(src + cp + l);
+                const uint32_t x = load32(src + pos + l) ^ load32(src + cp + (int32_t)l);
                 if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
                 l += 4u;
             }
             if (l > maxl) l = maxl;
-            if (l >= 4u) { mlen = l; dist = pos - cp; }
+            if (l >= 4u) { mlen = l; dist = (uint32_t)((int32_t)pos - cp); }
         }
         // greedy parse, sequential semantics, on the scalar unit: literals up to the next position that
         // has a match, take the match, jump past it
@@ -114,8 +125,14 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
             const uint32_t f = (uint32_t)__builtin_ctzll(mm);
             if (f > rel) start_mask |= (~0ull << rel) & ((1ull << f) - 1ull);
             start_mask |= 1ull << f;
+            const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)f);
+            // lazy evaluation (as zlib from level 4 up): a longer match one byte later wins, this byte goes out as a literal
+            if (f + 1u < tile_n && (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)(f + 1u)) > L) {
+                rel = f + 1u;
+                continue;
+            }
             match_mask |= 1ull << f;
-            rel = f + (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)f);
+            rel = f + L;
         }
         skip_until = p0 + rel;
         const bool my_start = (start_mask >> lane) & 1ull;

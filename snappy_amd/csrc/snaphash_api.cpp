@@ -354,7 +354,17 @@ void run_reads(const std::vector<Source>& src, const std::vector<ReadOp>& ops, s
                std::atomic<int64_t>& first_err_src)
 {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned T = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, ops.size() / 4));
+    // Staging-fill threads, measured on the GPU box (tools/copy_threads_sweep.sh): memcpy from caller memory
+    // peaks at 6 threads (44 GiB/s end to end; 16 threads: 33 -- they fight the concurrent H2D DMA for host
+    // memory bandwidth), pread of files at 12 (30 GiB/s).  SNAPHASH_COPY_THREADS overrides (1..256).
+    static const int forced = [] {
+        const char* e = getenv("SNAPHASH_COPY_THREADS");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= 256) ? v : 0;
+    }();
+    const bool from_memory = !ops.empty() && src[ops[0].src].mem != nullptr;
+    const unsigned cap = forced ? (unsigned)forced : (from_memory ? 6u : 12u);
+    const unsigned T = (unsigned)std::min<size_t>(std::min(cap, hw), std::max<size_t>(1, ops.size() / 4));
     std::atomic<size_t> next{0};
     auto worker = [&]() {
         for (;;) {

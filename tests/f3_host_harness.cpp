@@ -7,6 +7,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -34,12 +35,16 @@ uint32_t ld32(const uint8_t* p, const uint8_t* end) // like the kernel: bytes pa
     return v;
 }
 
-void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, std::vector<uint8_t>& out)
+// has_prev: the previous chunk lies in the same staging piece (the kernel seeds its table from it)
+void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool has_prev, std::vector<uint8_t>& out)
 {
     std::vector<uint8_t> z;
     BitW w(z);
     w.put(2, 3);
     std::vector<uint16_t> tab(1u << kHashBits, 0);
+    if (has_prev)
+        for (uint32_t p = 0; p < kChunk; ++p)
+            tab[(ld32(src - kChunk + p, bufend) * 0x9E3779B1u) >> (32 - kHashBits)] = (uint16_t)(p + 1);
     uint32_t skip_until = 0;
     for (uint32_t p0 = 0; p0 < len; p0 += 64) {
         uint32_t mlen[64] = {0}, dist[64] = {0}, word[64] = {0};
@@ -52,20 +57,23 @@ void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, std:
         }
         for (uint32_t i = 0; i < tile_n; ++i) {
             const uint32_t pos = p0 + i;
-            if (pos + 4 <= len) tab[(word[i] * 0x9E3779B1u) >> (32 - kHashBits)] = (uint16_t)(pos + 1);
+            if (pos + 4 <= len) tab[(word[i] * 0x9E3779B1u) >> (32 - kHashBits)] = (uint16_t)(pos + kChunk + 1);
         }
         for (uint32_t i = 0; i < tile_n; ++i) {
             const uint32_t pos = p0 + i;
             if (pos + 4 > len || !cand[i]) continue;
-            const uint32_t cp = cand[i] - 1, maxl = len - pos < 258 ? len - pos : 258;
+            const int64_t cp = (int64_t)cand[i] - 1 - kChunk;
+            const uint32_t maxl = len - pos < 258 ? len - pos : 258;
             uint32_t l = 0;
-            while (l < maxl && src[pos + l] == src[cp + l]) ++l;
-            if (l >= 4) { mlen[i] = l; dist[i] = pos - cp; }
+            while (l < maxl && src[pos + l] == src[cp + (int64_t)l]) ++l;
+            if (l >= 4) { mlen[i] = l; dist[i] = (uint32_t)((int64_t)pos - cp); }
         }
         uint32_t rel = skip_until > p0 ? skip_until - p0 : 0;
         while (rel < tile_n) {
             uint32_t bits, nb;
-            if (mlen[rel] >= 4) { enc_match(mlen[rel], dist[rel], bits, nb); w.put(bits, nb); rel += mlen[rel]; }
+            if (mlen[rel] >= 4 && rel + 1 < tile_n && mlen[rel + 1] > mlen[rel]) { // lazy: the next byte matches longer
+                enc_literal(word[rel] & 0xff, bits, nb); w.put(bits, nb); rel += 1;
+            } else if (mlen[rel] >= 4) { enc_match(mlen[rel], dist[rel], bits, nb); w.put(bits, nb); rel += mlen[rel]; }
             else { enc_literal(word[rel] & 0xff, bits, nb); w.put(bits, nb); rel += 1; }
         }
         skip_until = p0 + rel;
@@ -87,11 +95,16 @@ void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, std:
 
 extern "C" {
 
-// -> malloc'd gzip member; model of snaphash_gzip_buffer's output format
-uint8_t* f3_model_gzip(const uint8_t* in, size_t n, size_t* out_len)
+// -> malloc'd gzip member; model of snaphash_gzip_buffer's output.  piece = bytes per staging piece (a multiple of
+// the chunk size; 0 = everything in one): a chunk's table is seeded from the previous chunk only within a piece.
+uint8_t* f3_model_gzip2(const uint8_t* in, size_t n, size_t piece, size_t* out_len)
 {
     std::vector<uint8_t> out(kGzipHeader, kGzipHeader + 10);
-    for (size_t off = 0; off < n; off += kChunk) deflate_chunk(in + off, (uint32_t)(n - off < kChunk ? n - off : kChunk), in + n, out);
+    for (size_t off = 0; off < n; off += kChunk) {
+        const size_t pend = piece ? std::min(n, (off / piece + 1) * piece) : n; // the kernel never reads past its piece (+3)
+        const bool has_prev = piece ? (off % piece) != 0 : off != 0;
+        deflate_chunk(in + off, (uint32_t)(n - off < kChunk ? n - off : kChunk), in + pend, has_prev, out);
+    }
     out.push_back(0x03); out.push_back(0x00);
     const uint32_t crc = crc32_update(0, in, n);
     for (int k = 0; k < 4; ++k) out.push_back((uint8_t)(crc >> (8 * k)));
@@ -101,6 +114,7 @@ uint8_t* f3_model_gzip(const uint8_t* in, size_t n, size_t* out_len)
     *out_len = out.size();
     return p;
 }
+uint8_t* f3_model_gzip(const uint8_t* in, size_t n, size_t* out_len) { return f3_model_gzip2(in, n, 0, out_len); }
 
 uint32_t f3_crc32(uint32_t crc, const uint8_t* p, size_t n) { return crc32_update(crc, p, n); }
 uint32_t f3_crc32_combine(uint32_t a, uint32_t b, uint64_t len2) { return crc32_combine(a, b, len2); }

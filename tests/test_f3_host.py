@@ -25,6 +25,8 @@ def f3(tmp_path_factory):
     L = ctypes.CDLL(so)
     L.f3_model_gzip.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.f3_model_gzip.restype = ctypes.c_void_p
+    L.f3_model_gzip2.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.f3_model_gzip2.restype = ctypes.c_void_p
     L.f3_crc32.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
     L.f3_crc32.restype = ctypes.c_uint32
     L.f3_crc32_combine.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]
@@ -60,6 +62,11 @@ def test_model_of_the_deflate_kernel_is_valid_gzip(f3):
         assert gzip.decompress(gz) == data, name
         assert zlib.decompressobj(-15).decompress(gz[10:-8]) == data, name
         assert int.from_bytes(gz[-8:-4], "little") == zlib.crc32(data) and int.from_bytes(gz[-4:], "little") == len(data) & 0xffffffff
+        n2 = ctypes.c_size_t()
+        p2 = f3.f3_model_gzip2(data, len(data), 32768, ctypes.byref(n2))  # staging pieces of two chunks: no seeding across them
+        gz2 = ctypes.string_at(p2, n2.value)
+        f3.f3_free(p2)
+        assert gzip.decompress(gz2) == data and len(gz2) >= len(gz) - 8, name
         if name in ("zeros", "ff", "text"):
             assert len(gz) < len(data) // 8, (name, len(gz), len(data))
         if name == "prose":  # random words: single-candidate greedy LZ77 + fixed codes, ~0.56
@@ -153,3 +160,43 @@ def test_tar_name_too_long_is_refused(f3, tmp_path):
     open(os.path.join(root, "x" * 101), "w").close()  # no slash to split at: does not fit ustar
     out, n = ctypes.c_void_p(), ctypes.c_size_t()
     assert f3.f3_tar_stream(root.encode(), None, ctypes.byref(out), ctypes.byref(n)) == -6  # SNAPHASH_ENAME
+
+
+def test_f3_host_code_under_asan_and_ubsan(tmp_path):
+    """tarpack.cpp (walk, ustar headers, CRC-32), hostsha.cpp and the serial model of the DEFLATE kernel under
+    AddressSanitizer + UBSan (CPU build; GPU sanitizers are not available on the pool): a tree with every member
+    kind, names at the ustar limits, and all the sample inputs."""
+    exe = str(tmp_path / "asan_f3")
+    src = tmp_path / "driver.cpp"
+    src.write_text(r'''
+#include "%s/tests/f3_host_harness.cpp"
+#include "%s/snappy_amd/csrc/hostsha.cpp"
+#include <stdio.h>
+int main(int argc, char** argv) {
+    uint8_t* out = nullptr; size_t n = 0;
+    if (f3_tar_stream(argv[1], argv[2], &out, &n) != 0 || n %% 512) return 3;
+    size_t gz_len = 0;
+    uint8_t* gz = f3_model_gzip(out, n, &gz_len);            // the tar stream through the kernel's CPU model
+    if (!gz || gz_len < 18) return 4;
+    snaphash::HostSha hs; uint8_t dig[64];
+    snaphash::host_sha512_init(hs);
+    for (size_t off = 0; off < gz_len; off += 777) snaphash::host_sha512_update(hs, gz + off, gz_len - off < 777 ? gz_len - off : 777);
+    snaphash::host_sha512_final(hs, dig);
+    for (size_t len : {size_t(0), size_t(1), size_t(16383), size_t(16384), size_t(16385), size_t(70000)}) {
+        size_t m = 0; uint8_t* g2 = f3_model_gzip(out, len < n ? len : n, &m); f3_free(g2);
+    }
+    f3_free(gz); f3_free(out);
+    printf("asan f3 ok %%02x\n", dig[0]);
+    return 0;
+}
+''' % (ROOT, ROOT))
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-o", exe, str(src)])
+    root = str(tmp_path / "src")
+    os.makedirs(root)
+    _make_tree(root)
+    deep = os.path.join(root, *(["d" * 30] * 4))  # a 124-byte directory path: members below it need the ustar prefix split
+    os.makedirs(deep)
+    open(os.path.join(deep, "f" * 60), "w").write("prefix split")
+    r = subprocess.run([exe, root, root + "/DEBIAN"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"asan f3 ok" in r.stdout, r.stderr.decode()[-2000:]

@@ -32,7 +32,7 @@ def test_gpu_deflate_round_trips_and_equals_its_cpu_model(built_lib, f3):  # noq
             assert gzip.decompress(gz) == data, name
             assert int.from_bytes(gz[-8:-4], "little") == zlib.crc32(data), name
             n = ctypes.c_size_t()
-            p = f3.f3_model_gzip(data, len(data), ctypes.byref(n))
+            p = f3.f3_model_gzip2(data, len(data), 1 << 20, ctypes.byref(n))  # same staging piece size as the ctx
             model = ctypes.string_at(p, n.value)
             f3.f3_free(p)
             assert gz == model, name

@@ -35,12 +35,12 @@ uint32_t ld32(const uint8_t* p, const uint8_t* end) // like the kernel: bytes pa
     return v;
 }
 
-// has_prev: the previous chunk lies in the same staging piece (the kernel seeds its table from it)
-void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool has_prev, std::vector<uint8_t>& out)
+struct Tok { uint32_t lit, len, dist; }; // len == 0: literal
+
+// The kernel's parse of one chunk (pass 1 and pass 2 run it identically): hash table seeded from the previous
+// chunk, one candidate per position, greedy with one-byte lazy evaluation, tile by tile.
+void parse_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool has_prev, std::vector<Tok>& toks)
 {
-    std::vector<uint8_t> z;
-    BitW w(z);
-    w.put(2, 3);
     std::vector<uint16_t> tab(1u << kHashBits, 0);
     if (has_prev)
         for (uint32_t p = 0; p < kChunk; ++p)
@@ -70,17 +70,80 @@ void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool
         }
         uint32_t rel = skip_until > p0 ? skip_until - p0 : 0;
         while (rel < tile_n) {
-            uint32_t bits, nb;
             if (mlen[rel] >= 4 && rel + 1 < tile_n && mlen[rel + 1] > mlen[rel]) { // lazy: the next byte matches longer
-                enc_literal(word[rel] & 0xff, bits, nb); w.put(bits, nb); rel += 1;
-            } else if (mlen[rel] >= 4) { enc_match(mlen[rel], dist[rel], bits, nb); w.put(bits, nb); rel += mlen[rel]; }
-            else { enc_literal(word[rel] & 0xff, bits, nb); w.put(bits, nb); rel += 1; }
+                toks.push_back(Tok{word[rel] & 0xff, 0, 0}); rel += 1;
+            } else if (mlen[rel] >= 4) { toks.push_back(Tok{0, mlen[rel], dist[rel]}); rel += mlen[rel]; }
+            else { toks.push_back(Tok{word[rel] & 0xff, 0, 0}); rel += 1; }
         }
         skip_until = p0 + rel;
     }
-    w.put(0, 7);  // end of block
-    w.put(0, 3);  // empty stored block
-    w.align();
+}
+
+// has_prev: the previous chunk lies in the same staging piece (the kernel seeds its table from it)
+void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool has_prev, std::vector<uint8_t>& out)
+{
+    std::vector<Tok> toks;
+    parse_chunk(src, len, bufend, has_prev, toks);
+    // pass 1: symbol counts (every symbol starts at 1, so every symbol has a code) and the cost of both block kinds
+    uint32_t llf[kNumLL], df[kNumD];
+    for (int i = 0; i < kNumLL; ++i) llf[i] = 1;
+    for (int i = 0; i < kNumD; ++i) df[i] = 1;
+    uint64_t extra_bits = 0, fixed_bits = 3 + 7;
+    for (const Tok& t : toks) {
+        if (t.len == 0) { llf[t.lit]++; fixed_bits += fixed_ll_bits(t.lit); continue; }
+        uint32_t ls, le, lv, ds, de, dv;
+        len_symbol(t.len, ls, le, lv);
+        dist_symbol(t.dist, ds, de, dv);
+        llf[ls]++; df[ds]++;
+        extra_bits += le + de;
+        fixed_bits += fixed_ll_bits(ls) + 5;
+    }
+    llf[256]++;
+    fixed_bits += extra_bits;
+    uint8_t lll[kNumLL], dl[kNumD];
+    std::vector<uint32_t> w(2 * kNumLL), cnt(257), llc(kNumLL), dc(kNumD);
+    std::vector<uint16_t> parent(2 * kNumLL), order(kNumLL);
+    huff_lengths(llf, kNumLL, lll, w.data(), parent.data(), order.data(), cnt.data());
+    huff_lengths(df, kNumD, dl, w.data(), parent.data(), order.data(), cnt.data());
+    huff_codes(lll, kNumLL, llc.data(), cnt.data());
+    huff_codes(dl, kNumD, dc.data(), cnt.data());
+    uint64_t dyn_bits = kDynHeaderBits + extra_bits;
+    for (int i = 0; i < kNumLL; ++i) dyn_bits += (uint64_t)(llf[i] - 1) * lll[i];
+    for (int i = 0; i < kNumD; ++i) dyn_bits += (uint64_t)(df[i] - 1) * dl[i];
+    const bool dynamic = dyn_bits < fixed_bits;
+
+    std::vector<uint8_t> z;
+    BitW bw(z);
+    if (dynamic) {
+        bw.put(4, 3);                 // BFINAL=0, BTYPE=10
+        bw.put(kNumLL - 257, 5);
+        bw.put(kNumD - 1, 5);
+        bw.put(19 - 4, 4);
+        for (int k = 0; k < 19; ++k) bw.put(k < 3 ? 0 : 4, 3); // code length code: 16,17,18 unused, 0..15 four bits each
+        for (int i = 0; i < kNumLL; ++i) bw.put(rev_bits(lll[i], 4), 4);
+        for (int i = 0; i < kNumD; ++i) bw.put(rev_bits(dl[i], 4), 4);
+    } else {
+        bw.put(2, 3);
+    }
+    for (const Tok& t : toks) {
+        uint32_t bits, nb;
+        if (t.len == 0) {
+            if (dynamic) bw.put(llc[t.lit] >> 8, llc[t.lit] & 0xff);
+            else { enc_literal(t.lit, bits, nb); bw.put(bits, nb); }
+            continue;
+        }
+        if (!dynamic) { enc_match(t.len, t.dist, bits, nb); bw.put(bits, nb); continue; }
+        uint32_t ls, le, lv, ds, de, dv;
+        len_symbol(t.len, ls, le, lv);
+        dist_symbol(t.dist, ds, de, dv);
+        bw.put(llc[ls] >> 8, llc[ls] & 0xff);
+        bw.put(lv, le);
+        bw.put(dc[ds] >> 8, dc[ds] & 0xff);
+        bw.put(dv, de);
+    }
+    if (dynamic) bw.put(llc[256] >> 8, llc[256] & 0xff); else bw.put(0, 7);  // end of block
+    bw.put(0, 3);  // empty stored block
+    bw.align();
     z.push_back(0); z.push_back(0); z.push_back(0xff); z.push_back(0xff);
     if (z.size() >= len + 5u) {
         out.push_back(0);

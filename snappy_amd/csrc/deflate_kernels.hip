@@ -48,9 +48,11 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane)
 
 } // namespace
 
+constexpr uint32_t kTokStart = 1u << 31, kTokMatch = 1u << 30;
+
 // Per-wave LDS: hash table, bit buffer, symbol counts / codes, scratch of the code construction.
-// The scratch of the code construction is only live between the passes, when the table is about to be reset:
-// it lives inside the table's bytes.
+// The scratch of the code construction is live after the parse, when the table is spent: it lives inside the
+// table's bytes.
 struct HuffScratch {
     uint32_t w[2 * kNumLL];
     uint32_t cnt[260];
@@ -84,7 +86,7 @@ __device__ __forceinline__ void put_bits(uint32_t* ob, uint32_t at, uint32_t flu
 // emits a dynamic or a fixed block, whichever is smaller; a chunk that does not shrink is stored.
 __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __restrict__ in, uint64_t n_in,
                                                              uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
-                                                             uint32_t nchunks)
+                                                             uint32_t* __restrict__ toks, uint32_t nchunks)
 {
     __shared__ WaveLds s_lds[4];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -98,189 +100,195 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
     const uint8_t* src = in + base;
     uint8_t* dst = slots + (uint64_t)c * kDeflateSlot;
     uint32_t* dstw = reinterpret_cast<uint32_t*>(dst);
+    uint32_t* tok = toks + base; // one word per position: 0 = inside a match, kTokStart | byte, or kTokMatch | length << 16 | distance
 
+    // ---------------- pass 1: parse, count, remember the tokens ----------------
     for (uint32_t i = lane; i < 320u; i += 64u) L.freq[i] = 1u; // every symbol gets a code
-    uint32_t bitpos = 0, flushed = 0;
-    uint32_t fixed_bits = 3u + 7u, extra_bits = 0; // cost of a fixed block / extra bits of the matches (wave-uniform)
-    bool dynamic = false, overflow = false;
-
-    for (uint32_t pass = 0; pass < 2u; ++pass) {
-        for (uint32_t i = lane; i < kTab / 2u; i += 64u) reinterpret_cast<uint32_t*>(tab)[i] = 0u;
-        __builtin_amdgcn_wave_barrier();
-        // Window: the table is seeded with the previous chunk's positions (when this launch holds it), so a match may
-        // reach up to 32 KiB back across the chunk boundary -- the inflater does not care about block boundaries.
-        // Table entries are position + kDeflateChunk + 1 (0 = empty): previous-chunk positions are 1 .. kDeflateChunk.
-        if (c > 0u) {
-            const uint8_t* prev = src - kDeflateChunk;
-            for (uint32_t p = lane; p < kDeflateChunk; p += 64u) {
-                const uint32_t w = load32(prev + p);
-                tab[(w * 0x9E3779B1u) >> (32u - kHashBits)] = (uint16_t)(p + 1u);
-            }
-            __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < kTab / 2u; i += 64u) reinterpret_cast<uint32_t*>(tab)[i] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    // Window: the table is seeded with the previous chunk's positions (when this launch holds it), so a match may
+    // reach up to 32 KiB back across the chunk boundary -- the inflater does not care about block boundaries.
+    // Table entries are position + kDeflateChunk + 1 (0 = empty): previous-chunk positions are 1 .. kDeflateChunk.
+    if (c > 0u) {
+        const uint8_t* prev = src - kDeflateChunk;
+        for (uint32_t p = lane; p < kDeflateChunk; p += 64u) {
+            const uint32_t w = load32(prev + p);
+            tab[(w * 0x9E3779B1u) >> (32u - kHashBits)] = (uint16_t)(p + 1u);
         }
-        uint32_t skip_until = 0u; // first position not covered by an earlier match
-
-        for (uint32_t p0 = 0; p0 < len; p0 += 64u) {
-            const uint32_t pos = p0 + lane;
-            const bool valid = pos < len;
-            const bool canmatch = pos + 4u <= len;
-            uint32_t w = 0;
-            if (valid) w = load32(src + pos); // reads at most 3 bytes past the chunk: inside the padded input
-            const uint32_t h = (w * 0x9E3779B1u) >> (32u - kHashBits);
-            uint32_t cand = 0;
-            if (canmatch) cand = tab[h];
-            __builtin_amdgcn_wave_barrier();
-            if (canmatch) tab[h] = (uint16_t)(pos + kDeflateChunk + 1u); // lanes are served in order: the highest position stays
-            __builtin_amdgcn_wave_barrier();
-            uint32_t mlen = 0, dist = 0;
-            if (canmatch && cand != 0u) {
-                const int32_t cp = (int32_t)cand - 1 - (int32_t)kDeflateChunk; // an earlier tile or the previous chunk (< 0)
-                const uint32_t maxl = (len - pos < 258u) ? len - pos : 258u;
-                uint32_t l = 0;
-                while (l < maxl) {
-                    const uint32_t x = load32(src + pos + l) ^ load32(src + cp + (int32_t)l);
-                    if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
-                    l += 4u;
-                }
-                if (l > maxl) l = maxl;
-                if (l >= 4u) { mlen = l; dist = (uint32_t)((int32_t)pos - cp); }
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t fixed_bits = 3u + 7u, extra_bits = 0; // cost of a fixed block / extra bits of the matches (wave-uniform)
+    uint32_t skip_until = 0u;                      // first position not covered by an earlier match
+    for (uint32_t p0 = 0; p0 < len; p0 += 64u) {
+        const uint32_t pos = p0 + lane;
+        const bool valid = pos < len;
+        const bool canmatch = pos + 4u <= len;
+        uint32_t w = 0;
+        if (valid) w = load32(src + pos); // reads at most 3 bytes past the chunk: inside the padded input
+        const uint32_t h = (w * 0x9E3779B1u) >> (32u - kHashBits);
+        uint32_t cand = 0;
+        if (canmatch) cand = tab[h];
+        __builtin_amdgcn_wave_barrier();
+        if (canmatch) tab[h] = (uint16_t)(pos + kDeflateChunk + 1u); // lanes are served in order: the highest position stays
+        __builtin_amdgcn_wave_barrier();
+        uint32_t mlen = 0, dist = 0;
+        if (canmatch && cand != 0u) {
+            const int32_t cp = (int32_t)cand - 1 - (int32_t)kDeflateChunk; // an earlier tile or the previous chunk (< 0)
+            const uint32_t maxl = (len - pos < 258u) ? len - pos : 258u;
+            uint32_t l = 0;
+            while (l < maxl) {
+                const uint32_t x = load32(src + pos + l) ^ load32(src + cp + (int32_t)l);
+                if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                l += 4u;
             }
-            // greedy parse with one-byte lazy evaluation, sequential semantics, on the scalar unit
-            const uint64_t mm_all = __ballot(mlen >= 4u);
-            const uint32_t tile_n = (len - p0 < 64u) ? len - p0 : 64u;
-            uint64_t start_mask = 0, match_mask = 0;
-            uint32_t rel = (skip_until > p0) ? skip_until - p0 : 0u;
-            while (rel < tile_n) {
-                const uint64_t mm = mm_all & (~0ull << rel);
-                if (mm == 0ull) {
-                    start_mask |= (~0ull << rel) & ((tile_n == 64u) ? ~0ull : ((1ull << tile_n) - 1ull));
-                    rel = tile_n;
-                    break;
-                }
-                const uint32_t f = (uint32_t)__builtin_ctzll(mm);
-                if (f > rel) start_mask |= (~0ull << rel) & ((1ull << f) - 1ull);
-                start_mask |= 1ull << f;
-                const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)f);
-                // lazy evaluation (as zlib from level 4 up): a longer match one byte later wins, this byte goes out as a literal
-                if (f + 1u < tile_n && (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)(f + 1u)) > ml) {
-                    rel = f + 1u;
-                    continue;
-                }
-                match_mask |= 1ull << f;
-                rel = f + ml;
+            if (l > maxl) l = maxl;
+            if (l >= 4u) { mlen = l; dist = (uint32_t)((int32_t)pos - cp); }
+        }
+        // greedy parse with one-byte lazy evaluation, sequential semantics, on the scalar unit
+        const uint64_t mm_all = __ballot(mlen >= 4u);
+        const uint32_t tile_n = (len - p0 < 64u) ? len - p0 : 64u;
+        uint64_t start_mask = 0, match_mask = 0;
+        uint32_t rel = (skip_until > p0) ? skip_until - p0 : 0u;
+        while (rel < tile_n) {
+            const uint64_t mm = mm_all & (~0ull << rel);
+            if (mm == 0ull) {
+                start_mask |= (~0ull << rel) & ((tile_n == 64u) ? ~0ull : ((1ull << tile_n) - 1ull));
+                rel = tile_n;
+                break;
             }
-            skip_until = p0 + rel;
-            const bool my_start = (start_mask >> lane) & 1ull;
-            const bool my_match = (match_mask >> lane) & 1ull;
-            uint32_t ls = w & 0xffu, le = 0, lv = 0, ds = 0, de = 0, dv = 0;
-            if (my_match) { len_symbol(mlen, ls, le, lv); dist_symbol(dist, ds, de, dv); }
-
-            if (pass == 0u) { // count
-                uint32_t fb = 0, eb = 0;
-                if (my_start) {
-                    atomicAdd(&L.freq[ls], 1u);
-                    fb = fixed_ll_bits(ls);
-                    if (my_match) { atomicAdd(&L.freq[288u + ds], 1u); fb += 5u; eb = le + de; }
-                }
-                const uint32_t tf = wave_scan_incl(fb, lane), te = wave_scan_incl(eb, lane);
-                fixed_bits += (uint32_t)__builtin_amdgcn_readlane((int)tf, 63);
-                extra_bits += (uint32_t)__builtin_amdgcn_readlane((int)te, 63);
+            const uint32_t f = (uint32_t)__builtin_ctzll(mm);
+            if (f > rel) start_mask |= (~0ull << rel) & ((1ull << f) - 1ull);
+            start_mask |= 1ull << f;
+            const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)f);
+            // lazy evaluation (as zlib from level 4 up): a longer match one byte later wins, this byte goes out as a literal
+            if (f + 1u < tile_n && (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)(f + 1u)) > ml) {
+                rel = f + 1u;
                 continue;
             }
-            // emit: part A = literal/length code + its extra bits, part B = distance code + its extra bits (each <= 32 bits)
-            uint32_t ba = 0, na = 0, bb = 0, nbb = 0;
-            if (my_start) {
-                if (dynamic) {
-                    const uint32_t ca = L.freq[ls];
-                    ba = (ca >> 8) | (lv << (ca & 0xffu));
-                    na = (ca & 0xffu) + le;
-                    if (my_match) {
-                        const uint32_t cb = L.freq[288u + ds];
-                        bb = (cb >> 8) | (dv << (cb & 0xffu));
-                        nbb = (cb & 0xffu) + de;
-                    }
-                } else if (my_match) {
-                    enc_match(mlen, dist, ba, na);
-                } else {
-                    enc_literal(w & 0xffu, ba, na);
-                }
-            }
-            const uint32_t nb = na + nbb;
-            const uint32_t incl = wave_scan_incl(nb, lane);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (nb) {
-                const uint32_t at = bitpos + incl - nb;
-                put_bits(ob, at, flushed, ba);
-                if (nbb) put_bits(ob, at + na, flushed, bb);
-            }
-            bitpos += total;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t done = (bitpos >> 5) - flushed; // complete words in the buffer (< 34)
-            const uint32_t mine = ob[lane];
-            const uint32_t carry = ob[done];               // the partial word (uniform address: broadcast)
-            __builtin_amdgcn_wave_barrier();
-            if ((flushed + done) * 4u + 64u > kDeflateSlot) overflow = true; // cannot happen if both passes parse alike
-            if (lane < done && !overflow) dstw[flushed + lane] = mine;
-            ob[lane] = (lane == 0u) ? carry : 0u;
-            __builtin_amdgcn_wave_barrier();
-            flushed += done;
+            match_mask |= 1ull << f;
+            rel = f + ml;
         }
+        skip_until = p0 + rel;
+        const bool my_start = (start_mask >> lane) & 1ull;
+        const bool my_match = (match_mask >> lane) & 1ull;
+        uint32_t ls = w & 0xffu, le = 0, lv = 0, ds = 0, de = 0, dv = 0;
+        if (my_match) { len_symbol(mlen, ls, le, lv); dist_symbol(dist, ds, de, dv); }
+        uint32_t fb = 0, eb = 0, t = 0;
+        if (my_start) {
+            atomicAdd(&L.freq[ls], 1u);
+            fb = fixed_ll_bits(ls);
+            t = kTokStart | ls;
+            if (my_match) {
+                atomicAdd(&L.freq[288u + ds], 1u);
+                fb += 5u;
+                eb = le + de;
+                t = kTokStart | kTokMatch | (mlen << 16) | dist;
+            }
+        }
+        if (valid) tok[pos] = t;
+        const uint32_t tf = wave_scan_incl(fb, lane), te = wave_scan_incl(eb, lane);
+        fixed_bits += (uint32_t)__builtin_amdgcn_readlane((int)tf, 63);
+        extra_bits += (uint32_t)__builtin_amdgcn_readlane((int)te, 63);
+    }
 
-        if (pass == 0u) {
-            // ---- the codes: one lane, sequential and deterministic (the host model runs the same routines) ----
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0u) {
-                L.freq[256] += 1u; // end of block
-                HuffScratch& S = L.hs;
-                huff_lengths(L.freq, kNumLL, L.len, S.w, S.parent, S.order, S.cnt);
-                huff_lengths(L.freq + 288, kNumD, L.len + 288, S.w, S.parent, S.order, S.cnt);
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint32_t db = 0; // bits a dynamic block spends on the symbols
-            for (uint32_t i = lane; i < 318u; i += 64u)
-                if (i < (uint32_t)kNumLL || i >= 288u) db += (L.freq[i] - 1u) * (uint32_t)L.len[i];
-            const uint32_t dyn_bits = kDynHeaderBits + extra_bits + (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(db, lane), 63);
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0u) { // the counts are spent: the codes go where they were
-                huff_codes(L.len, kNumLL, L.freq, L.hs.cnt);
-                huff_codes(L.len + 288, kNumD, L.freq + 288, L.hs.cnt);
-            }
-            __builtin_amdgcn_wave_barrier();
-            fixed_bits += extra_bits;
-            dynamic = dyn_bits < fixed_bits;
-            // ---- block header into the bit buffer ----
-            ob[lane] = 0u;
-            __builtin_amdgcn_wave_barrier();
-            if (!dynamic) {
-                if (lane == 0u) ob[0] = 2u; // BFINAL=0, BTYPE=01: bits 0,1,0 LSB first
-                bitpos = 3u;
-            } else {
-                // BFINAL=0, BTYPE=10 | HLIT | HDIST | HCLEN | 19 x 3 bits (16,17,18 unused; 0..15: four bits each)
-                if (lane == 0u) {
-                    ob[0] = 4u | ((uint32_t)(kNumLL - 257) << 3) | ((uint32_t)(kNumD - 1) << 8) | (15u << 13) | (0u << 17);
-                    // bits 17..25: three zero lengths; bits 26..: sixteen times the value 4
-                }
-                // sixteen 3-bit fields "4" start at bit 26
-                if (lane < 16u) put_bits(ob, 26u + 3u * lane, 0u, 4u);
-                // one 4-bit code per code length (the code length code is the identity on 0..15, MSB first)
-                const uint32_t hdr0 = 3u + 14u + 57u;
-                for (uint32_t i = lane; i < (uint32_t)(kNumLL + kNumD); i += 64u) {
-                    const uint32_t l = (i < (uint32_t)kNumLL) ? L.len[i] : L.len[288u + i - (uint32_t)kNumLL];
-                    put_bits(ob, hdr0 + 4u * i, 0u, rev_bits(l, 4));
-                }
-                bitpos = kDynHeaderBits;
-            }
-            __builtin_amdgcn_wave_barrier();
-            flushed = 0u;
-            const uint32_t done = bitpos >> 5; // header words (<= 41): flush them now, keep the partial word
-            const uint32_t mine = ob[lane];
-            const uint32_t carry = ob[done];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < done) dstw[lane] = mine;
-            ob[lane] = (lane == 0u) ? carry : 0u;
-            __builtin_amdgcn_wave_barrier();
-            flushed = done;
+    // ---------------- the codes: one lane, sequential and deterministic (the host model runs the same routines) ----------------
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0u) {
+        L.freq[256] += 1u; // end of block
+        HuffScratch& S = L.hs;
+        huff_lengths(L.freq, kNumLL, L.len, S.w, S.parent, S.order, S.cnt);
+        huff_lengths(L.freq + 288, kNumD, L.len + 288, S.w, S.parent, S.order, S.cnt);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t db = 0; // bits a dynamic block spends on the symbols
+    for (uint32_t i = lane; i < 318u; i += 64u)
+        if (i < (uint32_t)kNumLL || i >= 288u) db += (L.freq[i] - 1u) * (uint32_t)L.len[i];
+    const uint32_t dyn_bits = kDynHeaderBits + extra_bits + (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(db, lane), 63);
+    fixed_bits += extra_bits;
+    const bool dynamic = dyn_bits < fixed_bits;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0u && dynamic) { // the counts are spent: the codes go where they were
+        huff_codes(L.len, kNumLL, L.freq, L.hs.cnt);
+        huff_codes(L.len + 288, kNumD, L.freq + 288, L.hs.cnt);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---------------- block header into the bit buffer ----------------
+    uint32_t bitpos, flushed;
+    ob[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (!dynamic) {
+        if (lane == 0u) ob[0] = 2u; // BFINAL=0, BTYPE=01: bits 0,1,0 LSB first
+        bitpos = 3u;
+    } else {
+        // BFINAL=0, BTYPE=10 | HLIT | HDIST | HCLEN | 19 x 3 bits: the code length code gives 16,17,18 no code and
+        // 0..15 four bits each, so it is the identity and every code length below goes out as four bits, MSB first
+        if (lane == 0u) ob[0] = 4u | ((uint32_t)(kNumLL - 257) << 3) | ((uint32_t)(kNumD - 1) << 8) | (15u << 13);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16u) put_bits(ob, 26u + 3u * lane, 0u, 4u); // bits 17..25: three zero lengths, then sixteen fours
+        const uint32_t hdr0 = 3u + 14u + 57u;
+        for (uint32_t i = lane; i < (uint32_t)(kNumLL + kNumD); i += 64u) {
+            const uint32_t l = (i < (uint32_t)kNumLL) ? L.len[i] : L.len[288u + i - (uint32_t)kNumLL];
+            put_bits(ob, hdr0 + 4u * i, 0u, rev_bits(l, 4));
         }
+        bitpos = kDynHeaderBits;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const uint32_t done = bitpos >> 5; // header words (<= 41): flush them now, keep the partial word
+        const uint32_t mine = ob[lane];
+        const uint32_t carry = ob[done];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < done) dstw[lane] = mine;
+        ob[lane] = (lane == 0u) ? carry : 0u;
+        __builtin_amdgcn_wave_barrier();
+        flushed = done;
+    }
+
+    // ---------------- pass 2: emit the remembered tokens ----------------
+    bool overflow = false;
+    for (uint32_t p0 = 0; p0 < len; p0 += 64u) {
+        const uint32_t pos = p0 + lane;
+        const uint32_t t = (pos < len) ? tok[pos] : 0u;
+        // part A = literal/length code + its extra bits, part B = distance code + its extra bits (each <= 32 bits)
+        uint32_t ba = 0, na = 0, bb = 0, nbb = 0;
+        if (t & kTokStart) {
+            if (dynamic) {
+                uint32_t ls = t & 0x1ffu, le = 0, lv = 0, ds = 0, de = 0, dv = 0;
+                if (t & kTokMatch) { len_symbol((t >> 16) & 0x1ffu, ls, le, lv); dist_symbol(t & 0xffffu, ds, de, dv); }
+                const uint32_t ca = L.freq[ls];
+                ba = (ca >> 8) | (lv << (ca & 0xffu));
+                na = (ca & 0xffu) + le;
+                if (t & kTokMatch) {
+                    const uint32_t cb = L.freq[288u + ds];
+                    bb = (cb >> 8) | (dv << (cb & 0xffu));
+                    nbb = (cb & 0xffu) + de;
+                }
+            } else if (t & kTokMatch) {
+                enc_match((t >> 16) & 0x1ffu, t & 0xffffu, ba, na);
+            } else {
+                enc_literal(t & 0xffu, ba, na);
+            }
+        }
+        const uint32_t nb = na + nbb;
+        const uint32_t incl = wave_scan_incl(nb, lane);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (nb) {
+            const uint32_t at = bitpos + incl - nb;
+            put_bits(ob, at, flushed, ba);
+            if (nbb) put_bits(ob, at + na, flushed, bb);
+        }
+        bitpos += total;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t done = (bitpos >> 5) - flushed; // complete words in the buffer (< 34)
+        const uint32_t mine = ob[lane];
+        const uint32_t carry = ob[done];               // the partial word (uniform address: broadcast)
+        __builtin_amdgcn_wave_barrier();
+        if ((flushed + done) * 4u + 64u > kDeflateSlot) overflow = true; // only a chunk that ends up stored comes here
+        if (lane < done && !overflow) dstw[flushed + lane] = mine;
+        ob[lane] = (lane == 0u) ? carry : 0u;
+        __builtin_amdgcn_wave_barrier();
+        flushed += done;
     }
 
     // end of block (fixed: seven 0 bits; dynamic: the code of symbol 256), then an empty stored block: 3 header
@@ -336,11 +344,12 @@ __global__ __launch_bounds__(256) void deflate_compact_kernel(const uint8_t* __r
     for (uint32_t i = (nw << 2) + threadIdx.x; i < n; i += 256u) dst[i] = src[i];
 }
 
-hipError_t launch_deflate_chunks(const uint8_t* d_in, uint64_t n_in, uint8_t* d_slots, uint32_t* d_sizes, uint32_t nchunks,
-                                 hipStream_t s)
+hipError_t launch_deflate_chunks(const uint8_t* d_in, uint64_t n_in, uint8_t* d_slots, uint32_t* d_sizes, uint32_t* d_toks,
+                                 uint32_t nchunks, hipStream_t s)
 {
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(deflate_chunks_kernel, dim3((nchunks + 3u) / 4u), dim3(256), 0, s, d_in, n_in, d_slots, d_sizes, nchunks);
+    hipLaunchKernelGGL(deflate_chunks_kernel, dim3((nchunks + 3u) / 4u), dim3(256), 0, s, d_in, n_in, d_slots, d_sizes, d_toks,
+                       nchunks);
     return hipGetLastError();
 }
 

@@ -97,6 +97,7 @@ struct DevCtx {
     // block-parallel DEFLATE scratch (row f3): per-chunk output slots, sizes, offsets, compacted output
     uint8_t* d_zslots = nullptr;
     uint8_t* d_zout = nullptr;
+    uint32_t* d_ztoks = nullptr; // the deflate kernel's parse, one word per staged byte
     uint32_t* d_zsizes = nullptr;
     uint64_t* d_zprefix = nullptr;
     uint32_t* h_zsizes = nullptr; // pinned
@@ -904,6 +905,7 @@ static void destroy_dev(DevCtx* c)
     if (c->d_digests) (void)hipFree(c->d_digests);
     if (c->d_zslots) (void)hipFree(c->d_zslots);
     if (c->d_zout) (void)hipFree(c->d_zout);
+    if (c->d_ztoks) (void)hipFree(c->d_ztoks);
     if (c->d_zsizes) (void)hipFree(c->d_zsizes);
     if (c->d_zprefix) (void)hipFree(c->d_zprefix);
     if (c->h_zsizes) (void)hipHostFree(c->h_zsizes);

@@ -381,6 +381,42 @@ def test_cli_tree_and_verify(built_lib, tmp_path):
     assert out.startswith("cf83e1357eefb8bd") and out.rstrip().endswith(tar)
 
 
+def test_cli_build_gzip_cmp(built_lib, oracle, tmp_path):
+    """The verbs over the round-2 entry points: `build` = tar.gz + hashes.yaml in one pass (the archive reads back
+    through tarfile, the yaml equals the oracle's over the tree and the archive the CLI wrote), `gzip`, `cmp`,
+    `dirupdated`, with the engine options."""
+    import gzip
+    import subprocess
+    import tarfile
+    cli = _cli()
+    build, _ = trees.make_simple_tree(str(tmp_path))
+    os.makedirs(os.path.join(build, "DEBIAN"), exist_ok=True)
+    out = str(tmp_path / "data.tar.gz")
+    r = subprocess.run([cli, "-t", "2", "-s", "build", build + "/", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert b"members" in r.stderr
+    assert r.stdout.decode().split()[0] == oracle.sha512(open(out, "rb").read()).hex()
+    assert open(os.path.join(build, "DEBIAN", "hashes.yaml"), "rb").read() == oracle.hashes_yaml(build, out)
+    names = tarfile.open(out, "r:gz").getnames()
+    assert "." not in names and names[0] == "./bin" and "./bin/bar" in names and not any("DEBIAN" in n for n in names)  # deb.go:310-314
+    z = str(tmp_path / "bar.gz")
+    src = os.path.join(build, "bin", "bar")
+    assert subprocess.run([cli, "gzip", src, z], timeout=120).returncode == 0
+    assert gzip.open(z).read() == open(src, "rb").read()
+    other = str(tmp_path / "bar2")
+    open(other, "wb").write(open(src, "rb").read() + b"x")
+    r = subprocess.run([cli, "-d", "0", "cmp", src, src, src, other], stdout=subprocess.PIPE, timeout=120)
+    assert r.returncode == 1
+    lines = r.stdout.decode().splitlines()
+    assert lines[0].startswith("equal") and lines[1].startswith("differ")
+    da, db = tmp_path / "a", tmp_path / "b"
+    da.mkdir(); db.mkdir()
+    (da / "same").write_bytes(b"1"); (db / "same").write_bytes(b"1")
+    (da / "changed").write_bytes(b"1"); (db / "changed").write_bytes(b"2")
+    r = subprocess.run([cli, "dirupdated", str(da), str(db), "pfx_"], stdout=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0 and r.stdout.decode().split() == ["pfx_changed"]
+
+
 def test_config_c2_on_disk_tree_scaled(built_lib, oracle):
     """BASELINE config 2 as a real on-disk tree (scaled to 1 500 x 1 MiB to keep the oracle in seconds;
     the full 10 000-file run is tools/e2e_tree.py, result in profiles/r01_e2e_tree_C2_full.txt):

@@ -29,12 +29,14 @@ namespace snaphash {
 
 namespace {
 
-constexpr uint32_t kHashBits = 12;
-constexpr uint32_t kTab = 1u << kHashBits;
+constexpr uint32_t kHashBits = 11;
+constexpr uint32_t kTab = 1u << kHashBits; // buckets of four candidates, newest first, in one 64-bit word
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 __device__ __forceinline__ uint32_t load32(const uint8_t* p) { return *reinterpret_cast<const u32_unaligned*>(p); }
+__device__ __forceinline__ uint64_t load64(const uint8_t* p) { return *reinterpret_cast<const u64_unaligned*>(p); }
 
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane)
 {
@@ -61,7 +63,7 @@ struct HuffScratch {
 };
 struct WaveLds {
     union {
-        uint16_t tab[kTab];
+        unsigned long long tab[kTab];
         HuffScratch hs;
     };
     uint32_t ob[64];
@@ -69,7 +71,7 @@ struct WaveLds {
                          // codes take the counts' place: code << 8 | length, same indexing
     uint8_t len[320];
 };
-static_assert(sizeof(HuffScratch) <= kTab * sizeof(uint16_t), "scratch must fit in the table");
+static_assert(sizeof(HuffScratch) <= kTab * sizeof(unsigned long long), "scratch must fit in the table");
 
 __device__ __forceinline__ void put_bits(uint32_t* ob, uint32_t at, uint32_t flushed, uint32_t bits)
 {
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
     const uint32_t c = blockIdx.x * 4u + wave;
     if (c >= nchunks) return; // whole wave
     WaveLds& L = s_lds[wave];
-    uint16_t* tab = L.tab;
+    unsigned long long* tab = L.tab;
     uint32_t* ob = L.ob;
     const uint64_t base = (uint64_t)c * kDeflateChunk;
     const uint32_t len = (uint32_t)((n_in - base < kDeflateChunk) ? (n_in - base) : kDeflateChunk);
@@ -104,18 +106,22 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
 
     // ---------------- pass 1: parse, count, remember the tokens ----------------
     for (uint32_t i = lane; i < 320u; i += 64u) L.freq[i] = 1u; // every symbol gets a code
-    for (uint32_t i = lane; i < kTab / 2u; i += 64u) reinterpret_cast<uint32_t*>(tab)[i] = 0u;
+    for (uint32_t i = lane; i < kTab; i += 64u) tab[i] = 0ull;
     __builtin_amdgcn_wave_barrier();
     // Window: the table is seeded with the previous chunk's positions (when this launch holds it), so a match may
     // reach up to 32 KiB back across the chunk boundary -- the inflater does not care about block boundaries.
-    // Table entries are position + kDeflateChunk + 1 (0 = empty): previous-chunk positions are 1 .. kDeflateChunk.
+    // Entries are position + kDeflateChunk + 1 (0 = empty): previous-chunk positions are 1 .. kDeflateChunk.
+    // A bucket is updated tile-wise: every lane reads its bucket, then offers (its entry, the three newest it read);
+    // of the lanes that share a bucket the highest position wins (atomic max: the entry is the most significant field).
     if (c > 0u) {
         const uint8_t* prev = src - kDeflateChunk;
         for (uint32_t p = lane; p < kDeflateChunk; p += 64u) {
-            const uint32_t w = load32(prev + p);
-            tab[(w * 0x9E3779B1u) >> (32u - kHashBits)] = (uint16_t)(p + 1u);
+            const uint32_t h = (load32(prev + p) * 0x9E3779B1u) >> (32u - kHashBits);
+            const unsigned long long old = tab[h];
+            __builtin_amdgcn_wave_barrier();
+            atomicMax(&tab[h], ((unsigned long long)(p + 1u) << 48) | (old >> 16));
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
     uint32_t fixed_bits = 3u + 7u, extra_bits = 0; // cost of a fixed block / extra bits of the matches (wave-uniform)
     uint32_t skip_until = 0u;                      // first position not covered by an earlier match
@@ -126,23 +132,29 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
         uint32_t w = 0;
         if (valid) w = load32(src + pos); // reads at most 3 bytes past the chunk: inside the padded input
         const uint32_t h = (w * 0x9E3779B1u) >> (32u - kHashBits);
-        uint32_t cand = 0;
+        unsigned long long cand = 0;
         if (canmatch) cand = tab[h];
         __builtin_amdgcn_wave_barrier();
-        if (canmatch) tab[h] = (uint16_t)(pos + kDeflateChunk + 1u); // lanes are served in order: the highest position stays
+        if (canmatch) atomicMax(&tab[h], ((unsigned long long)(pos + kDeflateChunk + 1u) << 48) | (cand >> 16));
         __builtin_amdgcn_wave_barrier();
         uint32_t mlen = 0, dist = 0;
-        if (canmatch && cand != 0u) {
-            const int32_t cp = (int32_t)cand - 1 - (int32_t)kDeflateChunk; // an earlier tile or the previous chunk (< 0)
+        if (canmatch) {
             const uint32_t maxl = (len - pos < 258u) ? len - pos : 258u;
-            uint32_t l = 0;
-            while (l < maxl) {
-                const uint32_t x = load32(src + pos + l) ^ load32(src + cp + (int32_t)l);
-                if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
-                l += 4u;
+            for (uint32_t k = 0; k < 4u; ++k) { // newest first; the longest wins, ties stay with the nearer one
+                const uint32_t e = (uint32_t)(cand >> (48u - 16u * k)) & 0xffffu;
+                if (e == 0u || mlen >= maxl) break;
+                const uint8_t* cs = src + ((int32_t)e - 1 - (int32_t)kDeflateChunk); // an earlier tile or the previous chunk
+                // to beat mlen the candidate must agree in the bytes mlen-3 .. mlen (all inside the chunk: mlen < maxl)
+                if (mlen >= 4u && load32(src + pos + mlen - 3u) != load32(cs + mlen - 3u)) continue;
+                uint32_t l = 0;
+                while (l < maxl) { // eight bytes a step: reads at most 7 bytes past the chunk's last byte
+                    const uint64_t x = load64(src + pos + l) ^ load64(cs + l);
+                    if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; break; }
+                    l += 8u;
+                }
+                if (l > maxl) l = maxl;
+                if (l >= 4u && l > mlen) { mlen = l; dist = (uint32_t)(src + pos - cs); }
             }
-            if (l > maxl) l = maxl;
-            if (l >= 4u) { mlen = l; dist = (uint32_t)((int32_t)pos - cp); }
         }
         // greedy parse with one-byte lazy evaluation, sequential semantics, on the scalar unit
         const uint64_t mm_all = __ballot(mlen >= 4u);

@@ -28,6 +28,7 @@
 #include <rccl/rccl.h> // types only: the library is dlopen'ed when a ctx owns several devices
 
 #include <condition_variable>
+#include <future>
 #include <memory>
 #include <mutex>
 
@@ -102,7 +103,8 @@ struct DevCtx {
     uint64_t* d_zprefix = nullptr;
     uint32_t* h_zsizes = nullptr; // pinned
     uint64_t* h_zprefix = nullptr;
-    uint8_t* h_zout = nullptr;
+    uint8_t* h_zout[2] = {nullptr, nullptr}; // pinned, double-buffered: the consumers read one while the next D2H fills the other
+    hipStream_t z_stream = nullptr;          // the compressor's stream
     size_t z_chunks = 0;
 
     std::vector<EventPair> ev_pool;
@@ -910,7 +912,8 @@ static void destroy_dev(DevCtx* c)
     if (c->d_zprefix) (void)hipFree(c->d_zprefix);
     if (c->h_zsizes) (void)hipHostFree(c->h_zsizes);
     if (c->h_zprefix) (void)hipHostFree(c->h_zprefix);
-    if (c->h_zout) (void)hipHostFree(c->h_zout);
+    for (uint8_t* z : c->h_zout) if (z) (void)hipHostFree(z);
+    if (c->z_stream) (void)hipStreamDestroy(c->z_stream);
     for (EventPair& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }

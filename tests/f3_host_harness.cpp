@@ -17,7 +17,7 @@
 using namespace snaphash;
 
 namespace {
-constexpr uint32_t kChunk = 16384, kHashBits = 12;
+constexpr uint32_t kChunk = 16384, kHashBits = 11;
 
 struct BitW {
     std::vector<uint8_t>& o;
@@ -37,36 +37,52 @@ uint32_t ld32(const uint8_t* p, const uint8_t* end) // like the kernel: bytes pa
 
 struct Tok { uint32_t lit, len, dist; }; // len == 0: literal
 
-// The kernel's parse of one chunk (pass 1 and pass 2 run it identically): hash table seeded from the previous
-// chunk, one candidate per position, greedy with one-byte lazy evaluation, tile by tile.
+// The kernel's parse of one chunk: a four-way bucket per hash value (newest first, one 64-bit word), updated
+// tile by tile -- every lane of a tile reads its bucket before any lane writes, and of the lanes that share a bucket
+// the highest position wins (the kernel's LDS atomic max) -- seeded the same way from the previous chunk; the longest
+// of the up to four candidates (ties: the nearest), greedy with one-byte lazy evaluation, tile by tile.
 void parse_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool has_prev, std::vector<Tok>& toks)
 {
-    std::vector<uint16_t> tab(1u << kHashBits, 0);
+    std::vector<uint64_t> tab(1u << kHashBits, 0);
+    auto hash = [](uint32_t w) { return (w * 0x9E3779B1u) >> (32 - kHashBits); };
+    // entry = position + kChunk + 1 (0 = empty): the previous chunk's positions are 1 .. kChunk
+    auto tile_update = [&](const uint32_t* word, const uint64_t* old, uint32_t first_entry, uint32_t n) {
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t v = ((uint64_t)(first_entry + i) << 48) | (old[i] >> 16);
+            uint64_t& t = tab[hash(word[i])];
+            if (v > t) t = v;
+        }
+    };
     if (has_prev)
-        for (uint32_t p = 0; p < kChunk; ++p)
-            tab[(ld32(src - kChunk + p, bufend) * 0x9E3779B1u) >> (32 - kHashBits)] = (uint16_t)(p + 1);
+        for (uint32_t p0 = 0; p0 < kChunk; p0 += 64) {
+            uint32_t word[64];
+            uint64_t old[64];
+            for (uint32_t i = 0; i < 64; ++i) { word[i] = ld32(src - kChunk + p0 + i, bufend); old[i] = tab[hash(word[i])]; }
+            tile_update(word, old, p0 + 1, 64);
+        }
     uint32_t skip_until = 0;
     for (uint32_t p0 = 0; p0 < len; p0 += 64) {
         uint32_t mlen[64] = {0}, dist[64] = {0}, word[64] = {0};
-        uint32_t cand[64] = {0};
+        uint64_t cand[64] = {0};
         const uint32_t tile_n = len - p0 < 64 ? len - p0 : 64;
+        uint32_t n_can = 0; // positions with four bytes left: a prefix of the tile
         for (uint32_t i = 0; i < tile_n; ++i) { // all lanes read the table before any lane writes it
             const uint32_t pos = p0 + i;
             word[i] = ld32(src + pos, bufend);
-            if (pos + 4 <= len) cand[i] = tab[(word[i] * 0x9E3779B1u) >> (32 - kHashBits)];
+            if (pos + 4 <= len) { cand[i] = tab[hash(word[i])]; n_can = i + 1; }
         }
-        for (uint32_t i = 0; i < tile_n; ++i) {
+        tile_update(word, cand, p0 + kChunk + 1, n_can);
+        for (uint32_t i = 0; i < n_can; ++i) {
             const uint32_t pos = p0 + i;
-            if (pos + 4 <= len) tab[(word[i] * 0x9E3779B1u) >> (32 - kHashBits)] = (uint16_t)(pos + kChunk + 1);
-        }
-        for (uint32_t i = 0; i < tile_n; ++i) {
-            const uint32_t pos = p0 + i;
-            if (pos + 4 > len || !cand[i]) continue;
-            const int64_t cp = (int64_t)cand[i] - 1 - kChunk;
             const uint32_t maxl = len - pos < 258 ? len - pos : 258;
-            uint32_t l = 0;
-            while (l < maxl && src[pos + l] == src[cp + (int64_t)l]) ++l;
-            if (l >= 4) { mlen[i] = l; dist[i] = (uint32_t)((int64_t)pos - cp); }
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = (uint32_t)(cand[i] >> (48 - 16 * k)) & 0xffffu;
+                if (!e) break;
+                const int64_t cp = (int64_t)e - 1 - kChunk;
+                uint32_t l = 0;
+                while (l < maxl && src[pos + l] == src[cp + (int64_t)l]) ++l;
+                if (l >= 4 && l > mlen[i]) { mlen[i] = l; dist[i] = (uint32_t)((int64_t)pos - cp); }
+            }
         }
         uint32_t rel = skip_until > p0 ? skip_until - p0 : 0;
         while (rel < tile_n) {

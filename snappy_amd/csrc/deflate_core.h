@@ -75,18 +75,20 @@ DF_HD void enc_match(uint32_t len, uint32_t dist, uint32_t& bits, uint32_t& n)
 } // namespace snaphash
 
 // ---- dynamic Huffman blocks (RFC 1951 sec. 3.2.7) -----------------------------------------------------------
-// Per chunk the kernel runs its parse twice: the first pass only counts symbols, then ONE lane builds the two
-// codes with the sequential, deterministic routines below (the host model in tests/ runs the very same code), the
-// second pass emits with them.  Code lengths come from a plain two-queue Huffman construction over counting-
-// sorted frequencies; if the tree is deeper than 15 the frequencies are halved and it is rebuilt.
+// Per chunk the kernel parses once, counting symbols and remembering its tokens, then ONE lane builds the codes and
+// the block header with the sequential, deterministic routines below (the host model in tests/ runs the very same
+// code), and a second pass emits the tokens with them.  Code lengths come from a plain two-queue Huffman
+// construction over counting-sorted frequencies (symbols that do not occur get no code); if the tree is deeper than
+// the limit the frequencies are halved and it is rebuilt.  The two sequences of code lengths are run-length coded
+// and Huffman coded themselves, as the format provides (symbols 16, 17, 18).
 
 namespace snaphash {
 
-constexpr int kNumLL = 286; // literal/length symbols sent (HLIT = 29)
-constexpr int kNumD = 30;   // distance symbols sent (HDIST = 29)
+constexpr int kNumLL = 286; // literal/length symbols
+constexpr int kNumD = 30;   // distance symbols
+constexpr int kNumCL = 19;  // symbols of the code length code
 constexpr int kMaxBits = 15;
-// 3 block header bits + HLIT/HDIST/HCLEN + 19 x 3 bits + one 4-bit code per code length (no run-length codes)
-constexpr uint32_t kDynHeaderBits = 3 + 5 + 5 + 4 + 19 * 3 + (kNumLL + kNumD) * 4;
+constexpr int kMaxCLBits = 7;
 
 DF_HD void len_symbol(uint32_t len, uint32_t& sym, uint32_t& ebits, uint32_t& eval)
 {
@@ -116,19 +118,19 @@ DF_HD void dist_symbol(uint32_t dist, uint32_t& sym, uint32_t& ebits, uint32_t& 
 // bits a fixed-Huffman block spends on one literal/length symbol (without extra bits)
 DF_HD uint32_t fixed_ll_bits(uint32_t sym) { return sym < 144u ? 8u : (sym < 256u ? 9u : (sym < 280u ? 7u : 8u)); }
 
-// Code lengths (1..kMaxBits) for n symbols, freq[i] >= 1.  Scratch: w[2n] u32, parent[2n] u16, order[n] u16,
-// cnt[257] u32.  Deterministic: stable counting sort (ties by symbol index), ties between a leaf and an internal
-// node go to the leaf.
+// Code lengths (1..max_bits; 0 for a symbol with freq 0) for n symbols.  Scratch: w[2n] u32, parent[2n] u16,
+// order[n] u16, cnt[257] u32.  Deterministic: stable counting sort (ties by symbol index), ties between a leaf and
+// an internal node go to the leaf.  A single used symbol gets length 1.
 template <typename U32P, typename U16P>
-DF_HD_CALL void huff_lengths(const U32P freq, int n, uint8_t* len, U32P w, U16P parent, U16P order, U32P cnt)
+DF_HD_CALL void huff_lengths(const U32P freq, int n, uint32_t max_bits, uint8_t* len, U32P w, U16P parent, U16P order, U32P cnt)
 {
     for (uint32_t shift = 0;; ++shift) {
-        // stable radix sort of the symbols by (freq >> shift, at least 1), two 8-bit passes
+        // stable radix sort of the symbols by key = 0 (unused) or freq >> shift clamped to 1..0xffff, two 8-bit passes
         for (int pass = 0; pass < 2; ++pass) {
             for (int k = 0; k <= 256; ++k) cnt[k] = 0;
             for (int i = 0; i < n; ++i) {
                 uint32_t f = freq[i] >> shift;
-                if (f == 0) f = 1;
+                if (f == 0 && freq[i] != 0) f = 1;
                 if (f > 0xffffu) f = 0xffffu;
                 cnt[((f >> (8 * pass)) & 0xffu) + 1u]++;
             }
@@ -137,20 +139,26 @@ DF_HD_CALL void huff_lengths(const U32P freq, int n, uint8_t* len, U32P w, U16P 
             for (int i = 0; i < n; ++i) {
                 const int sym = pass ? (int)parent[i] : i;
                 uint32_t f = freq[sym] >> shift;
-                if (f == 0) f = 1;
+                if (f == 0 && freq[sym] != 0) f = 1;
                 if (f > 0xffffu) f = 0xffffu;
                 const uint32_t at = cnt[(f >> (8 * pass)) & 0xffu]++;
                 if (pass) order[at] = (uint16_t)sym;
                 else parent[at] = (uint16_t)sym;
             }
         }
-        // two-queue merge: leaves in sorted order (node id = position in `order`), internal nodes n .. 2n-2
-        for (int i = 0; i < n; ++i) {
+        int z = 0; // unused symbols sort first
+        while (z < n && freq[order[z]] == 0) { len[order[z]] = 0; ++z; }
+        const int m = n - z;
+        if (m == 0) return;
+        if (m == 1) { len[order[z]] = 1; return; }
+        // two-queue merge: leaves in sorted order (node id = position in `order`), internal nodes n .. n+m-2
+        for (int i = z; i < n; ++i) {
             uint32_t f = freq[order[i]] >> shift;
+            if (f > 0xffffu) f = 0xffffu;
             w[i] = f ? f : 1u;
         }
-        int li = 0, ii = n, nn = n; // heads of the leaf and internal queues, next internal node
-        for (int k = 0; k < n - 1; ++k) {
+        int li = z, ii = n, nn = n; // heads of the leaf and internal queues, next internal node
+        for (int k = 0; k < m - 1; ++k) {
             int a, b;
             if (li < n && (ii >= nn || w[li] <= w[ii])) a = li++; else a = ii++;
             if (li < n && (ii >= nn || w[li] <= w[ii])) b = li++; else b = ii++;
@@ -160,14 +168,14 @@ DF_HD_CALL void huff_lengths(const U32P freq, int n, uint8_t* len, U32P w, U16P 
             ++nn;
         }
         // depths, root first (internal nodes were created in increasing order, so a parent has the larger id)
-        w[2 * n - 2] = 0;
+        w[nn - 1] = 0;
         uint32_t deepest = 0;
-        for (int node = 2 * n - 3; node >= 0; --node) {
+        for (int node = nn - 2; node >= z; --node) {
             w[node] = w[parent[node]] + 1u;
             if (node < n && w[node] > deepest) deepest = w[node];
         }
-        if (deepest <= (uint32_t)kMaxBits) {
-            for (int i = 0; i < n; ++i) len[order[i]] = (uint8_t)w[i];
+        if (deepest <= max_bits) {
+            for (int i = z; i < n; ++i) len[order[i]] = (uint8_t)w[i];
             return;
         }
     }
@@ -191,6 +199,84 @@ DF_HD_CALL void huff_codes(const uint8_t* len, int n, U32P out, U32P scratch)
     for (int i = 0; i < n; ++i) {
         const uint32_t l = len[i];
         out[i] = l ? ((rev_bits(next[l]++, l) << 8) | l) : 0u;
+    }
+}
+
+// The header of a dynamic block, as data: what write_dyn_header() sends.
+struct DynHeader {
+    uint32_t nll;   // literal/length code lengths sent (HLIT + 257)
+    uint32_t nd;    // distance code lengths sent (HDIST + 1)
+    uint32_t ncl;   // code length code lengths sent (HCLEN + 4)
+    uint32_t ntok;  // run-length tokens
+    uint32_t bits;  // whole header, the three block-type bits included
+};
+
+DF_HD uint32_t cl_order(uint32_t i) // RFC 1951 sec. 3.2.7: the order in which the code length code lengths are sent
+{
+    // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
+    if (i < 3u) return 16u + i;
+    if (i == 3u) return 0u;
+    const uint32_t k = i - 4u; // 8,7,9,6,10,5,...: 8 + (k+1)/2 alternating down/up
+    return (k & 1u) ? 8u - ((k + 1u) >> 1) : 8u + (k >> 1);
+}
+
+// Run-length codes the code lengths of both alphabets (as ONE sequence, runs may cross from one into the other),
+// builds the code length code.  tok[i] = symbol | extra value << 8.  clfreq/cl_len/cl_code: kNumCL entries.
+// Scratch as huff_lengths (for n = kNumCL).
+template <typename U32P, typename U16P>
+DF_HD_CALL void build_dyn_header(const uint8_t* ll_len, const uint8_t* d_len, U16P tok, U32P clfreq, uint8_t* cl_len, U32P cl_code,
+                                 U32P w, U16P parent, U16P order, U32P cnt, DynHeader& h)
+{
+    uint32_t nll = kNumLL, nd = kNumD;
+    while (nll > 257u && ll_len[nll - 1u] == 0) --nll;
+    while (nd > 1u && d_len[nd - 1u] == 0) --nd;
+    for (int k = 0; k < kNumCL; ++k) clfreq[k] = 0;
+    const uint32_t total = nll + nd;
+    uint32_t nt = 0, i = 0;
+    while (i < total) {
+        const uint32_t v = i < nll ? ll_len[i] : d_len[i - nll];
+        uint32_t run = 1;
+        while (i + run < total && (i + run < nll ? ll_len[i + run] : d_len[i + run - nll]) == v) ++run;
+        i += run;
+        if (v == 0) {
+            while (run >= 11u) { const uint32_t r = run < 138u ? run : 138u; tok[nt++] = (uint16_t)(18u | ((r - 11u) << 8)); clfreq[18]++; run -= r; }
+            if (run >= 3u) { tok[nt++] = (uint16_t)(17u | ((run - 3u) << 8)); clfreq[17]++; run = 0; }
+        } else {
+            tok[nt++] = (uint16_t)v; clfreq[v]++; --run;
+            while (run >= 3u) { const uint32_t r = run < 6u ? run : 6u; tok[nt++] = (uint16_t)(16u | ((r - 3u) << 8)); clfreq[16]++; run -= r; }
+        }
+        for (; run; --run) { tok[nt++] = (uint16_t)v; clfreq[v]++; }
+    }
+    // an inflater wants a complete code length code: at least two symbols
+    uint32_t used = 0;
+    for (int k = 0; k < kNumCL; ++k) used += clfreq[k] != 0;
+    if (used < 2u) { if (clfreq[0] == 0) clfreq[0] = 1; else clfreq[1] = 1; }
+    huff_lengths(clfreq, kNumCL, (uint32_t)kMaxCLBits, cl_len, w, parent, order, cnt);
+    huff_codes(cl_len, kNumCL, cl_code, cnt);
+    uint32_t ncl = kNumCL;
+    while (ncl > 4u && cl_len[cl_order(ncl - 1u)] == 0) --ncl;
+    uint32_t bits = 3u + 5u + 5u + 4u + 3u * ncl;
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t sym = tok[t] & 0xffu;
+        bits += cl_len[sym] + (sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u);
+    }
+    h.nll = nll; h.nd = nd; h.ncl = ncl; h.ntok = nt; h.bits = bits;
+}
+
+// Sends the header through sink(bits, nbits) (LSB first, nbits <= 16 per call).
+template <typename U32P, typename U16P, typename Sink>
+DF_HD void write_dyn_header(const DynHeader& h, const U16P tok, const uint8_t* cl_len, const U32P cl_code, Sink&& sink)
+{
+    sink(4u, 3u); // BFINAL=0, BTYPE=10
+    sink(h.nll - 257u, 5u);
+    sink(h.nd - 1u, 5u);
+    sink(h.ncl - 4u, 4u);
+    for (uint32_t k = 0; k < h.ncl; ++k) sink((uint32_t)cl_len[cl_order(k)], 3u);
+    for (uint32_t t = 0; t < h.ntok; ++t) {
+        const uint32_t sym = tok[t] & 0xffu, ev = (uint32_t)tok[t] >> 8;
+        const uint32_t c = cl_code[sym];
+        sink(c >> 8, c & 0xffu);
+        if (sym >= 16u) sink(ev, sym == 16u ? 2u : sym == 17u ? 3u : 7u);
     }
 }
 

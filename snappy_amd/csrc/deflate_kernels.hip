@@ -31,6 +31,7 @@ namespace {
 
 constexpr uint32_t kHashBits = 11;
 constexpr uint32_t kTab = 1u << kHashBits; // buckets of four candidates, newest first, in one 64-bit word
+constexpr uint32_t kGroup = 16;            // positions that look the table up together, before any of them enters it
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
@@ -60,6 +61,13 @@ struct HuffScratch {
     uint32_t cnt[260];
     uint16_t parent[2 * kNumLL];
     uint16_t order[kNumLL + 2];
+    // the block header: run-length tokens of the code lengths, the code length code
+    uint16_t rle[kNumLL + kNumD + 4];
+    uint32_t clfreq[kNumCL + 1];
+    uint32_t clcode[kNumCL + 1];
+    uint8_t cllen[kNumCL + 1];
+    DynHeader hdr;
+    uint32_t hdr_tail; // the header's last, partial word
 };
 struct WaveLds {
     union {
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
     uint32_t* tok = toks + base; // one word per position: 0 = inside a match, kTokStart | byte, or kTokMatch | length << 16 | distance
 
     // ---------------- pass 1: parse, count, remember the tokens ----------------
-    for (uint32_t i = lane; i < 320u; i += 64u) L.freq[i] = 1u; // every symbol gets a code
+    for (uint32_t i = lane; i < 320u; i += 64u) L.freq[i] = 0u;
     for (uint32_t i = lane; i < kTab; i += 64u) tab[i] = 0ull;
     __builtin_amdgcn_wave_barrier();
     // Window: the table is seeded with the previous chunk's positions (when this launch holds it), so a match may
@@ -117,10 +125,13 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
         const uint8_t* prev = src - kDeflateChunk;
         for (uint32_t p = lane; p < kDeflateChunk; p += 64u) {
             const uint32_t h = (load32(prev + p) * 0x9E3779B1u) >> (32u - kHashBits);
-            const unsigned long long old = tab[h];
-            __builtin_amdgcn_wave_barrier();
-            atomicMax(&tab[h], ((unsigned long long)(p + 1u) << 48) | (old >> 16));
-            __builtin_amdgcn_wave_barrier();
+            for (uint32_t g = 0; g < 64u / kGroup; ++g) {
+                if (lane / kGroup == g) {
+                    const unsigned long long old = tab[h];
+                    atomicMax(&tab[h], ((unsigned long long)(p + 1u) << 48) | (old >> 16));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     uint32_t fixed_bits = 3u + 7u, extra_bits = 0; // cost of a fixed block / extra bits of the matches (wave-uniform)
@@ -133,10 +144,13 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
         if (valid) w = load32(src + pos); // reads at most 3 bytes past the chunk: inside the padded input
         const uint32_t h = (w * 0x9E3779B1u) >> (32u - kHashBits);
         unsigned long long cand = 0;
-        if (canmatch) cand = tab[h];
-        __builtin_amdgcn_wave_barrier();
-        if (canmatch) atomicMax(&tab[h], ((unsigned long long)(pos + kDeflateChunk + 1u) << 48) | (cand >> 16));
-        __builtin_amdgcn_wave_barrier();
+        for (uint32_t g = 0; g < 64u / kGroup; ++g) { // a group sees what the groups before it in the tile have entered
+            if (canmatch && lane / kGroup == g) {
+                cand = tab[h];
+                atomicMax(&tab[h], ((unsigned long long)(pos + kDeflateChunk + 1u) << 48) | (cand >> 16));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         uint32_t mlen = 0, dist = 0;
         if (canmatch) {
             const uint32_t maxl = (len - pos < 258u) ? len - pos : 258u;
@@ -203,59 +217,49 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
         extra_bits += (uint32_t)__builtin_amdgcn_readlane((int)te, 63);
     }
 
-    // ---------------- the codes: one lane, sequential and deterministic (the host model runs the same routines) ----------------
+    // ---------------- the codes and the header: one lane, sequential and deterministic (the host model runs the same routines) ----------------
     __builtin_amdgcn_wave_barrier();
+    HuffScratch& S = L.hs;
     if (lane == 0u) {
         L.freq[256] += 1u; // end of block
-        HuffScratch& S = L.hs;
-        huff_lengths(L.freq, kNumLL, L.len, S.w, S.parent, S.order, S.cnt);
-        huff_lengths(L.freq + 288, kNumD, L.len + 288, S.w, S.parent, S.order, S.cnt);
+        if (L.freq[288] == 0u) L.freq[288] = 1u; // at least two distance codes, as zlib sends
+        if (L.freq[289] == 0u) L.freq[289] = 1u;
+        huff_lengths(L.freq, kNumLL, (uint32_t)kMaxBits, L.len, S.w, S.parent, S.order, S.cnt);
+        huff_lengths(L.freq + 288, kNumD, (uint32_t)kMaxBits, L.len + 288, S.w, S.parent, S.order, S.cnt);
+        build_dyn_header(L.len, L.len + 288, S.rle, S.clfreq, S.cllen, S.clcode, S.w, S.parent, S.order, S.cnt, S.hdr);
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t db = 0; // bits a dynamic block spends on the symbols
     for (uint32_t i = lane; i < 318u; i += 64u)
-        if (i < (uint32_t)kNumLL || i >= 288u) db += (L.freq[i] - 1u) * (uint32_t)L.len[i];
-    const uint32_t dyn_bits = kDynHeaderBits + extra_bits + (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(db, lane), 63);
+        if (i < (uint32_t)kNumLL || i >= 288u) db += L.freq[i] * (uint32_t)L.len[i];
+    const uint32_t hdr_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.hdr.bits);
+    const uint32_t dyn_bits = hdr_bits + extra_bits + (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(db, lane), 63);
     fixed_bits += extra_bits;
     const bool dynamic = dyn_bits < fixed_bits;
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0u && dynamic) { // the counts are spent: the codes go where they were
-        huff_codes(L.len, kNumLL, L.freq, L.hs.cnt);
-        huff_codes(L.len + 288, kNumD, L.freq + 288, L.hs.cnt);
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // ---------------- block header into the bit buffer ----------------
-    uint32_t bitpos, flushed;
-    ob[lane] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    if (!dynamic) {
-        if (lane == 0u) ob[0] = 2u; // BFINAL=0, BTYPE=01: bits 0,1,0 LSB first
-        bitpos = 3u;
-    } else {
-        // BFINAL=0, BTYPE=10 | HLIT | HDIST | HCLEN | 19 x 3 bits: the code length code gives 16,17,18 no code and
-        // 0..15 four bits each, so it is the identity and every code length below goes out as four bits, MSB first
-        if (lane == 0u) ob[0] = 4u | ((uint32_t)(kNumLL - 257) << 3) | ((uint32_t)(kNumD - 1) << 8) | (15u << 13);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 16u) put_bits(ob, 26u + 3u * lane, 0u, 4u); // bits 17..25: three zero lengths, then sixteen fours
-        const uint32_t hdr0 = 3u + 14u + 57u;
-        for (uint32_t i = lane; i < (uint32_t)(kNumLL + kNumD); i += 64u) {
-            const uint32_t l = (i < (uint32_t)kNumLL) ? L.len[i] : L.len[288u + i - (uint32_t)kNumLL];
-            put_bits(ob, hdr0 + 4u * i, 0u, rev_bits(l, 4));
+    if (lane == 0u) {
+        if (dynamic) {
+            // the counts are spent: the codes go where they were
+            huff_codes(L.len, kNumLL, L.freq, S.cnt);
+            huff_codes(L.len + 288, kNumD, L.freq + 288, S.cnt);
+            // the header goes straight to the slot, whole words; its partial last word opens the bit buffer
+            uint64_t acc = 0;
+            uint32_t nacc = 0, widx = 0;
+            write_dyn_header(S.hdr, S.rle, S.cllen, S.clcode, [&](uint32_t bits, uint32_t nb) {
+                acc |= (uint64_t)bits << nacc;
+                nacc += nb;
+                if (nacc >= 32u) { dstw[widx++] = (uint32_t)acc; acc >>= 32; nacc -= 32u; }
+            });
+            S.hdr_tail = (uint32_t)acc;
+        } else {
+            S.hdr_tail = 2u; // BFINAL=0, BTYPE=01: bits 0,1,0 LSB first
         }
-        bitpos = kDynHeaderBits;
     }
     __builtin_amdgcn_wave_barrier();
-    {
-        const uint32_t done = bitpos >> 5; // header words (<= 41): flush them now, keep the partial word
-        const uint32_t mine = ob[lane];
-        const uint32_t carry = ob[done];
-        __builtin_amdgcn_wave_barrier();
-        if (lane < done) dstw[lane] = mine;
-        ob[lane] = (lane == 0u) ? carry : 0u;
-        __builtin_amdgcn_wave_barrier();
-        flushed = done;
-    }
+    uint32_t bitpos = dynamic ? hdr_bits : 3u;
+    uint32_t flushed = bitpos >> 5;
+    ob[lane] = (lane == 0u) ? S.hdr_tail : 0u;
+    __builtin_amdgcn_wave_barrier();
 
     // ---------------- pass 2: emit the remembered tokens ----------------
     bool overflow = false;

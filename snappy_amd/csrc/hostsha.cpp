@@ -1,8 +1,9 @@
-// hostsha.cpp -- the library's own SHA-512 on host cores, used ONLY by the opt-in
+// hostsha.cpp -- the library's own SHA-512 on host cores, used by the opt-in
 // hybrid scheduler (snaphash_config.host_threads > 0): streams whose single-stream
 // time on the GPU would exceed the batch makespan (a lone stream advances at
-// ~40 MB/s on MI355X, a host core at ~0.5 GB/s) are hashed here, concurrently
-// with the GPU batch.  Same compression function as the kernels (sha512_core.h,
+// ~45 MB/s on MI355X, a host core at ~1.4 GB/s) are hashed here, concurrently
+// with the GPU batch -- and by the data.tar.gz producer for the archive digest, the
+// one stream of that pass that cannot be parallel.  Same compression function as the kernels (sha512_core.h,
 // FIPS 180-4), continuing from any chaining value, so a stream may also start on
 // the GPU and finish here.  This is not a fallback: without a gfx950 device
 // snaphash_init still fails, and with host_threads == 0 (the default) nothing in
@@ -18,6 +19,10 @@
 #include <unistd.h>
 
 #include <vector>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "sha512_core.h"
 
@@ -45,6 +50,48 @@ void host_sha512_resume(HostSha& s, const uint64_t H[8], uint64_t total_prev)
 #define HS_S1(x) (HS_ROTR(x, 14) ^ HS_ROTR(x, 18) ^ HS_ROTR(x, 41))
 #define HS_s0(x) (HS_ROTR(x, 1) ^ HS_ROTR(x, 8) ^ ((x) >> 7))
 #define HS_s1(x) (HS_ROTR(x, 19) ^ HS_ROTR(x, 61) ^ ((x) >> 6))
+// HS_ASSOC picks how a round is associated (tools/hostsha_bench.cpp measures them; EPYC 9575F, AVX-512VL schedule:
+// 0/1 1.34 GB/s, 2 1.42, 3 1.43 -- hashlib/OpenSSL on the same core: 1.33)
+#ifndef HS_ASSOC
+#define HS_ASSOC 3
+#endif
+#if HS_ASSOC == 2 || HS_ASSOC == 3
+// Both recurrences at Sigma (3 deep) + one add: e' = ((d + h + kw) + Ch) + Sigma1(e), a' = ((T1 + Maj) + Sigma0(a));
+// the sums that do not hang on e or a are formed first.
+#if HS_ASSOC == 3
+#define HS_KEEP(x) asm("" : "+r"(x))
+#else
+#define HS_KEEP(x) (void)0
+#endif
+#define HS_RND(a, b, c, d, e, f, g, h, kw)                                   \
+    do {                                                                    \
+        uint64_t hk_ = h + (kw);                                            \
+        uint64_t dhk_ = d + hk_;                                            \
+        HS_KEEP(hk_);                                                       \
+        HS_KEEP(dhk_);                                                      \
+        const uint64_t ch_ = ((f ^ g) & e) ^ g;                             \
+        const uint64_t s1_ = HS_S1(e);                                      \
+        uint64_t x_ = dhk_ + ch_;                                           \
+        uint64_t y_ = hk_ + ch_;                                            \
+        HS_KEEP(x_);                                                        \
+        HS_KEEP(y_);                                                        \
+        d = x_ + s1_;                                                       \
+        const uint64_t t1_ = y_ + s1_;                                      \
+        uint64_t z_ = t1_ + ((a & (b | c)) | (b & c));                      \
+        HS_KEEP(z_);                                                        \
+        h = z_ + HS_S0(a);                                                  \
+    } while (0)
+#elif HS_ASSOC
+#define HS_RND(a, b, c, d, e, f, g, h, kw)                                   \
+    do {                                                                    \
+        /* everything that does not hang on e first: the chain through e is Sigma1, one add, one add */ \
+        uint64_t t1_ = (h + (kw)) + (g ^ (e & (f ^ g)));                    \
+        t1_ += HS_S1(e);                                                    \
+        const uint64_t t2_ = HS_S0(a) + ((a & b) | (c & (a | b)));          \
+        d += t1_;                                                           \
+        h = t1_ + t2_;                                                      \
+    } while (0)
+#else
 #define HS_RND(a, b, c, d, e, f, g, h, kw)                                   \
     do {                                                                    \
         const uint64_t t1_ = h + HS_S1(e) + (g ^ (e & (f ^ g))) + (kw);      \
@@ -52,6 +99,7 @@ void host_sha512_resume(HostSha& s, const uint64_t H[8], uint64_t total_prev)
         d += t1_;                                                           \
         h = t1_ + t2_;                                                      \
     } while (0)
+#endif
 
 __attribute__((target_clones("default", "bmi2"))) static void blocks(uint64_t H[8], const uint8_t* p, size_t nblocks)
 {
@@ -89,7 +137,104 @@ __attribute__((target_clones("default", "bmi2"))) static void blocks(uint64_t H[
     }
     H[0] = a; H[1] = b; H[2] = c; H[3] = d; H[4] = e; H[5] = f; H[6] = g; H[7] = h;
 }
-static inline void block(uint64_t H[8], const uint8_t* p) { blocks(H, p, 1); }
+
+// The same block function with the message schedule on the vector unit (two schedule words per 128-bit operation,
+// W[t..t+1] = W[t-16..] + s0(W[t-15..]) + W[t-7..] + s1(W[t-2..])), interleaved with the scalar rounds two by two:
+// the rounds are a serial chain through e (~6 cycles per round), the schedule is independent work that fits beside
+// it on the vector pipes.  Two spellings: AVX-512VL (64-bit vector rotates, three-input xor) and AVX2 (shifts).
+#if defined(__x86_64__)
+#define HS_VEC_BODY(S0V, S1V)                                                                                        \
+    const __m128i bswap = _mm_set_epi64x(0x08090a0b0c0d0e0fLL, 0x0001020304050607LL);                                \
+    uint64_t a = H[0], b = H[1], c = H[2], d = H[3], e = H[4], f = H[5], g = H[6], h = H[7];                         \
+    alignas(16) uint64_t kw[16];                                                                                     \
+    for (; nblocks; --nblocks, p += 128) {                                                                           \
+        __m128i X0 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 0)), bswap);                              \
+        __m128i X1 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 16)), bswap);                             \
+        __m128i X2 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 32)), bswap);                             \
+        __m128i X3 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 48)), bswap);                             \
+        __m128i X4 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 64)), bswap);                             \
+        __m128i X5 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 80)), bswap);                             \
+        __m128i X6 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 96)), bswap);                             \
+        __m128i X7 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 112)), bswap);                            \
+        const uint64_t sa = a, sb = b, sc = c, sd = d, se = e, sf = f, sg = g, sh = h;                               \
+        const uint64_t* K = K512;                                                                                    \
+        /* step i: K+W of rounds 2i, 2i+1 to the stack, the two rounds, then the words sixteen rounds ahead */       \
+        _Pragma("GCC unroll 1") for (int t = 0; t < 64; t += 16, K += 16)                                           \
+        {                                                                                                            \
+            HS_VSTEP(X0, X1, X4, X5, X7, 0, a, b, c, d, e, f, g, h, S0V, S1V);                                        \
+            HS_VSTEP(X1, X2, X5, X6, X0, 2, g, h, a, b, c, d, e, f, S0V, S1V);                                        \
+            HS_VSTEP(X2, X3, X6, X7, X1, 4, e, f, g, h, a, b, c, d, S0V, S1V);                                        \
+            HS_VSTEP(X3, X4, X7, X0, X2, 6, c, d, e, f, g, h, a, b, S0V, S1V);                                        \
+            HS_VSTEP(X4, X5, X0, X1, X3, 8, a, b, c, d, e, f, g, h, S0V, S1V);                                        \
+            HS_VSTEP(X5, X6, X1, X2, X4, 10, g, h, a, b, c, d, e, f, S0V, S1V);                                       \
+            HS_VSTEP(X6, X7, X2, X3, X5, 12, e, f, g, h, a, b, c, d, S0V, S1V);                                       \
+            HS_VSTEP(X7, X0, X3, X4, X6, 14, c, d, e, f, g, h, a, b, S0V, S1V);                                       \
+        }                                                                                                            \
+        HS_VLAST(X0, 0, a, b, c, d, e, f, g, h);                                                                     \
+        HS_VLAST(X1, 2, g, h, a, b, c, d, e, f);                                                                     \
+        HS_VLAST(X2, 4, e, f, g, h, a, b, c, d);                                                                     \
+        HS_VLAST(X3, 6, c, d, e, f, g, h, a, b);                                                                     \
+        HS_VLAST(X4, 8, a, b, c, d, e, f, g, h);                                                                     \
+        HS_VLAST(X5, 10, g, h, a, b, c, d, e, f);                                                                    \
+        HS_VLAST(X6, 12, e, f, g, h, a, b, c, d);                                                                    \
+        HS_VLAST(X7, 14, c, d, e, f, g, h, a, b);                                                                    \
+        a += sa; b += sb; c += sc; d += sd; e += se; f += sf; g += sg; h += sh;                                      \
+    }                                                                                                                \
+    H[0] = a; H[1] = b; H[2] = c; H[3] = d; H[4] = e; H[5] = f; H[6] = g; H[7] = h;
+
+// XA = W[t..t+1] (becomes W[t+16..t+17]), XB = W[t+2..], XE/XF = W[t+8..]/W[t+10..], XH = W[t+14..t+15]
+#define HS_VSTEP(XA, XB, XE, XF, XH, i, a, b, c, d, e, f, g, h, S0V, S1V)                                             \
+    _mm_store_si128((__m128i*)(kw + (i)), _mm_add_epi64(XA, _mm_loadu_si128((const __m128i*)(K + (i)))));             \
+    HS_RND(a, b, c, d, e, f, g, h, kw[(i)]);                                                                         \
+    HS_RND(h, a, b, c, d, e, f, g, kw[(i) + 1]);                                                                     \
+    XA = _mm_add_epi64(_mm_add_epi64(XA, S0V(_mm_alignr_epi8(XB, XA, 8))),                                           \
+                       _mm_add_epi64(_mm_alignr_epi8(XF, XE, 8), S1V(XH)))
+#define HS_VLAST(XA, i, a, b, c, d, e, f, g, h)                                                                      \
+    _mm_store_si128((__m128i*)(kw + (i)), _mm_add_epi64(XA, _mm_loadu_si128((const __m128i*)(K + (i)))));             \
+    HS_RND(a, b, c, d, e, f, g, h, kw[(i)]);                                                                         \
+    HS_RND(h, a, b, c, d, e, f, g, kw[(i) + 1])
+
+#define HS_S0V_512(x) _mm_ternarylogic_epi64(_mm_ror_epi64(x, 1), _mm_ror_epi64(x, 8), _mm_srli_epi64(x, 7), 0x96)
+#define HS_S1V_512(x) _mm_ternarylogic_epi64(_mm_ror_epi64(x, 19), _mm_ror_epi64(x, 61), _mm_srli_epi64(x, 6), 0x96)
+#define HS_VROR(x, n) _mm_or_si128(_mm_srli_epi64(x, n), _mm_slli_epi64(x, 64 - (n)))
+#define HS_S0V_AVX2(x) _mm_xor_si128(_mm_xor_si128(HS_VROR(x, 1), HS_VROR(x, 8)), _mm_srli_epi64(x, 7))
+#define HS_S1V_AVX2(x) _mm_xor_si128(_mm_xor_si128(HS_VROR(x, 19), HS_VROR(x, 61)), _mm_srli_epi64(x, 6))
+
+__attribute__((target("avx512f,avx512vl,bmi2"))) static void blocks_avx512(uint64_t H[8], const uint8_t* p, size_t nblocks)
+{
+    HS_VEC_BODY(HS_S0V_512, HS_S1V_512)
+}
+__attribute__((target("avx2,bmi2"))) static void blocks_avx2(uint64_t H[8], const uint8_t* p, size_t nblocks)
+{
+    HS_VEC_BODY(HS_S0V_AVX2, HS_S1V_AVX2)
+}
+
+typedef void (*BlocksFn)(uint64_t*, const uint8_t*, size_t);
+static BlocksFn pick_blocks()
+{
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2")) return blocks_avx512;
+    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")) return blocks_avx2;
+    return blocks;
+}
+static const BlocksFn blocks_best = pick_blocks();
+#else
+static void (*const blocks_best)(uint64_t*, const uint8_t*, size_t) = blocks;
+#endif
+
+// which block function a build runs (tests: every spelling must agree)
+int host_sha512_variants() { return 3; }
+void host_sha512_blocks_variant(int v, uint64_t H[8], const uint8_t* p, size_t nblocks)
+{
+#if defined(__x86_64__)
+    if (v == 1 && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")) return blocks_avx2(H, p, nblocks);
+    if (v == 2 && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2")) return blocks_avx512(H, p, nblocks);
+#endif
+    blocks(H, p, nblocks);
+}
+
+static inline void block(uint64_t H[8], const uint8_t* p) { blocks_best(H, p, 1); }
+
 
 void host_sha512_update(HostSha& s, const uint8_t* p, size_t n)
 {
@@ -106,7 +251,7 @@ void host_sha512_update(HostSha& s, const uint8_t* p, size_t n)
     }
     if (n >= 128) {
         const size_t nb = n >> 7;
-        blocks(s.H, p, nb);
+        blocks_best(s.H, p, nb);
         p += nb << 7;
         n &= 127;
     }

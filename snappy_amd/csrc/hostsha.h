@@ -22,4 +22,9 @@ void host_sha512_final(HostSha& s, uint8_t out[64]);
 // Returns 0 or an errno.
 int host_sha512_file_from(HostSha& s, const char* path, uint64_t offset, uint64_t expect_len, uint8_t out[64]);
 
+// The block function exists in several spellings (portable/BMI2, AVX2 schedule, AVX-512VL schedule), picked once by
+// CPU features; tests run every one the CPU supports: variant v in [0, host_sha512_variants()), unsupported -> portable.
+int host_sha512_variants();
+void host_sha512_blocks_variant(int v, uint64_t H[8], const uint8_t* p, size_t nblocks);
+
 } // namespace snaphash

@@ -74,6 +74,13 @@ extern "C" void hostsha_buffer(const uint8_t* data, uint64_t n, uint64_t split, 
     host_sha512_update(a, data, n);
     host_sha512_final(a, out);
 }
+// chaining value after nblocks blocks through spelling v of the block function (portable, AVX2, AVX-512VL)
+extern "C" int hostsha_variants() { return host_sha512_variants(); }
+extern "C" void hostsha_blocks_variant(int v, const uint8_t* data, uint64_t nblocks, uint64_t* H_out)
+{
+    for (int k = 0; k < 8; ++k) H_out[k] = IV512[k];
+    host_sha512_blocks_variant(v, H_out, data, (size_t)nblocks);
+}
 extern "C" int hostsha_file(const char* path, uint64_t expect, uint8_t* out)
 {
     HostSha a;

@@ -17,7 +17,7 @@
 using namespace snaphash;
 
 namespace {
-constexpr uint32_t kChunk = 16384, kHashBits = 11;
+constexpr uint32_t kChunk = 16384, kHashBits = 11, kGroup = 16;
 
 struct BitW {
     std::vector<uint8_t>& o;
@@ -38,9 +38,10 @@ uint32_t ld32(const uint8_t* p, const uint8_t* end) // like the kernel: bytes pa
 struct Tok { uint32_t lit, len, dist; }; // len == 0: literal
 
 // The kernel's parse of one chunk: a four-way bucket per hash value (newest first, one 64-bit word), updated
-// tile by tile -- every lane of a tile reads its bucket before any lane writes, and of the lanes that share a bucket
-// the highest position wins (the kernel's LDS atomic max) -- seeded the same way from the previous chunk; the longest
-// of the up to four candidates (ties: the nearest), greedy with one-byte lazy evaluation, tile by tile.
+// in groups of kGroup positions -- every lane of a group reads its bucket before any lane of the group writes, and of
+// the lanes that share a bucket the highest position wins (the kernel's LDS atomic max) -- seeded the same way from
+// the previous chunk; the longest of the up to four candidates (ties: the nearest), greedy with one-byte lazy
+// evaluation, tile (64 positions) by tile.
 void parse_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool has_prev, std::vector<Tok>& toks)
 {
     std::vector<uint64_t> tab(1u << kHashBits, 0);
@@ -57,8 +58,11 @@ void parse_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool h
         for (uint32_t p0 = 0; p0 < kChunk; p0 += 64) {
             uint32_t word[64];
             uint64_t old[64];
-            for (uint32_t i = 0; i < 64; ++i) { word[i] = ld32(src - kChunk + p0 + i, bufend); old[i] = tab[hash(word[i])]; }
-            tile_update(word, old, p0 + 1, 64);
+            for (uint32_t i = 0; i < 64; ++i) word[i] = ld32(src - kChunk + p0 + i, bufend);
+            for (uint32_t g0 = 0; g0 < 64; g0 += kGroup) {
+                for (uint32_t i = g0; i < g0 + kGroup; ++i) old[i] = tab[hash(word[i])];
+                tile_update(word + g0, old + g0, p0 + g0 + 1, kGroup);
+            }
         }
     uint32_t skip_until = 0;
     for (uint32_t p0 = 0; p0 < len; p0 += 64) {
@@ -66,12 +70,15 @@ void parse_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool h
         uint64_t cand[64] = {0};
         const uint32_t tile_n = len - p0 < 64 ? len - p0 : 64;
         uint32_t n_can = 0; // positions with four bytes left: a prefix of the tile
-        for (uint32_t i = 0; i < tile_n; ++i) { // all lanes read the table before any lane writes it
-            const uint32_t pos = p0 + i;
-            word[i] = ld32(src + pos, bufend);
-            if (pos + 4 <= len) { cand[i] = tab[hash(word[i])]; n_can = i + 1; }
+        for (uint32_t i = 0; i < tile_n; ++i) {
+            word[i] = ld32(src + p0 + i, bufend);
+            if (p0 + i + 4 <= len) n_can = i + 1;
         }
-        tile_update(word, cand, p0 + kChunk + 1, n_can);
+        for (uint32_t g0 = 0; g0 < n_can; g0 += kGroup) {
+            const uint32_t gn = std::min<uint32_t>(kGroup, n_can - g0);
+            for (uint32_t i = g0; i < g0 + gn; ++i) cand[i] = tab[hash(word[i])];
+            tile_update(word + g0, cand + g0, p0 + g0 + kChunk + 1, gn);
+        }
         for (uint32_t i = 0; i < n_can; ++i) {
             const uint32_t pos = p0 + i;
             const uint32_t maxl = len - pos < 258 ? len - pos : 258;
@@ -100,10 +107,8 @@ void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool
 {
     std::vector<Tok> toks;
     parse_chunk(src, len, bufend, has_prev, toks);
-    // pass 1: symbol counts (every symbol starts at 1, so every symbol has a code) and the cost of both block kinds
-    uint32_t llf[kNumLL], df[kNumD];
-    for (int i = 0; i < kNumLL; ++i) llf[i] = 1;
-    for (int i = 0; i < kNumD; ++i) df[i] = 1;
+    // symbol counts and the cost of both block kinds
+    uint32_t llf[kNumLL] = {0}, df[kNumD] = {0};
     uint64_t extra_bits = 0, fixed_bits = 3 + 7;
     for (const Tok& t : toks) {
         if (t.len == 0) { llf[t.lit]++; fixed_bits += fixed_ll_bits(t.lit); continue; }
@@ -115,32 +120,27 @@ void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool
         fixed_bits += fixed_ll_bits(ls) + 5;
     }
     llf[256]++;
+    if (df[0] == 0) df[0] = 1; // at least two distance codes, as zlib sends (old inflaters want a complete code)
+    if (df[1] == 0) df[1] = 1;
     fixed_bits += extra_bits;
-    uint8_t lll[kNumLL], dl[kNumD];
-    std::vector<uint32_t> w(2 * kNumLL), cnt(257), llc(kNumLL), dc(kNumD);
-    std::vector<uint16_t> parent(2 * kNumLL), order(kNumLL);
-    huff_lengths(llf, kNumLL, lll, w.data(), parent.data(), order.data(), cnt.data());
-    huff_lengths(df, kNumD, dl, w.data(), parent.data(), order.data(), cnt.data());
+    uint8_t lll[kNumLL], dl[kNumD], cll[kNumCL];
+    std::vector<uint32_t> w(2 * kNumLL), cnt(257), llc(kNumLL), dc(kNumD), clf(kNumCL), clc(kNumCL);
+    std::vector<uint16_t> parent(2 * kNumLL), order(kNumLL), rle(kNumLL + kNumD);
+    huff_lengths(llf, kNumLL, (uint32_t)kMaxBits, lll, w.data(), parent.data(), order.data(), cnt.data());
+    huff_lengths(df, kNumD, (uint32_t)kMaxBits, dl, w.data(), parent.data(), order.data(), cnt.data());
+    DynHeader hdr;
+    build_dyn_header(lll, dl, rle.data(), clf.data(), cll, clc.data(), w.data(), parent.data(), order.data(), cnt.data(), hdr);
     huff_codes(lll, kNumLL, llc.data(), cnt.data());
     huff_codes(dl, kNumD, dc.data(), cnt.data());
-    uint64_t dyn_bits = kDynHeaderBits + extra_bits;
-    for (int i = 0; i < kNumLL; ++i) dyn_bits += (uint64_t)(llf[i] - 1) * lll[i];
-    for (int i = 0; i < kNumD; ++i) dyn_bits += (uint64_t)(df[i] - 1) * dl[i];
+    uint64_t dyn_bits = hdr.bits + extra_bits;
+    for (int i = 0; i < kNumLL; ++i) dyn_bits += (uint64_t)llf[i] * lll[i];
+    for (int i = 0; i < kNumD; ++i) dyn_bits += (uint64_t)df[i] * dl[i];
     const bool dynamic = dyn_bits < fixed_bits;
 
     std::vector<uint8_t> z;
     BitW bw(z);
-    if (dynamic) {
-        bw.put(4, 3);                 // BFINAL=0, BTYPE=10
-        bw.put(kNumLL - 257, 5);
-        bw.put(kNumD - 1, 5);
-        bw.put(19 - 4, 4);
-        for (int k = 0; k < 19; ++k) bw.put(k < 3 ? 0 : 4, 3); // code length code: 16,17,18 unused, 0..15 four bits each
-        for (int i = 0; i < kNumLL; ++i) bw.put(rev_bits(lll[i], 4), 4);
-        for (int i = 0; i < kNumD; ++i) bw.put(rev_bits(dl[i], 4), 4);
-    } else {
-        bw.put(2, 3);
-    }
+    if (dynamic) write_dyn_header(hdr, rle.data(), cll, clc.data(), [&](uint32_t bits, uint32_t nb) { bw.put(bits, nb); });
+    else bw.put(2, 3);
     for (const Tok& t : toks) {
         uint32_t bits, nb;
         if (t.len == 0) {

@@ -71,6 +71,16 @@ def test_host_sha512_of_the_hybrid_scheduler(core, tmp_path_factory):
         for split in (0, 128, 256, 1024):
             L.hostsha_buffer(rnd[:n], n, split, out)
             assert out.raw == hashlib.sha512(rnd[:n]).digest(), (n, split)
+    # every spelling of the block function this CPU can run agrees with the portable one, block count by block count
+    L.hostsha_blocks_variant.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    data = os.urandom(128 * 9)
+    for nblocks in range(0, 10):
+        got = []
+        for v in range(L.hostsha_variants()):
+            H = (ctypes.c_uint64 * 8)()
+            L.hostsha_blocks_variant(v, data, nblocks, H)
+            got.append(list(H))
+        assert all(g == got[0] for g in got), nblocks
     p = tmp_path_factory.mktemp("f") / "blob"
     blob = os.urandom((1 << 20) + 77)
     p.write_bytes(blob)

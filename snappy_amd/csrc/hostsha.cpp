@@ -55,30 +55,31 @@ void host_sha512_resume(HostSha& s, const uint64_t H[8], uint64_t total_prev)
 #ifndef HS_ASSOC
 #define HS_ASSOC 3
 #endif
+#define HS_KEEP(x) asm("" : "+r"(x)) /* the compiler keeps this association */
 #if HS_ASSOC == 2 || HS_ASSOC == 3
 // Both recurrences at Sigma (3 deep) + one add: e' = ((d + h + kw) + Ch) + Sigma1(e), a' = ((T1 + Maj) + Sigma0(a));
 // the sums that do not hang on e or a are formed first.
 #if HS_ASSOC == 3
-#define HS_KEEP(x) asm("" : "+r"(x))
+#define HS_KEEP3(x) HS_KEEP(x)
 #else
-#define HS_KEEP(x) (void)0
+#define HS_KEEP3(x) (void)0
 #endif
 #define HS_RND(a, b, c, d, e, f, g, h, kw)                                   \
     do {                                                                    \
         uint64_t hk_ = h + (kw);                                            \
         uint64_t dhk_ = d + hk_;                                            \
-        HS_KEEP(hk_);                                                       \
-        HS_KEEP(dhk_);                                                      \
+        HS_KEEP3(hk_);                                                       \
+        HS_KEEP3(dhk_);                                                      \
         const uint64_t ch_ = ((f ^ g) & e) ^ g;                             \
         const uint64_t s1_ = HS_S1(e);                                      \
         uint64_t x_ = dhk_ + ch_;                                           \
         uint64_t y_ = hk_ + ch_;                                            \
-        HS_KEEP(x_);                                                        \
-        HS_KEEP(y_);                                                        \
+        HS_KEEP3(x_);                                                        \
+        HS_KEEP3(y_);                                                        \
         d = x_ + s1_;                                                       \
         const uint64_t t1_ = y_ + s1_;                                      \
         uint64_t z_ = t1_ + ((a & (b | c)) | (b & c));                      \
-        HS_KEEP(z_);                                                        \
+        HS_KEEP3(z_);                                                        \
         h = z_ + HS_S0(a);                                                  \
     } while (0)
 #elif HS_ASSOC
@@ -204,16 +205,142 @@ __attribute__((target("avx512f,avx512vl,bmi2"))) static void blocks_avx512(uint6
 {
     HS_VEC_BODY(HS_S0V_512, HS_S1V_512)
 }
+// AVX-512VL, second spelling: the a-recurrence lives on the vector unit as well (a, b, c in xmm registers: Sigma0 is
+// three vprorq + one vpternlogq, Maj one vpternlogq), the e-recurrence stays scalar.  T1 crosses to the vector side
+// every round, c crosses back as the next round's d (computed three rounds earlier, so its latency is hidden).
+// That leaves the scalar pipes 15 operations a round instead of 26, and both recurrences are 4 cycles deep -- on
+// paper.  Measured on EPYC 9575F: 0.87 GB/s against 1.43 for the spelling above (the two register-file crossings a
+// round cost more than the operations they save): kept as a tested variant, never picked.
+#define HS_KW(XA, i) _mm_store_si128((__m128i*)(kw + (i)), _mm_add_epi64(XA, _mm_loadu_si128((const __m128i*)(K + (i)))))
+#define HS_SCHED(XA, XB, XE, XF, XH)                                                                     \
+    XA = _mm_add_epi64(_mm_add_epi64(XA, HS_S0V_512(_mm_alignr_epi8(XB, XA, 8))),                       \
+                       _mm_add_epi64(_mm_alignr_epi8(XF, XE, 8), HS_S1V_512(XH)))
+// state (a, b, c | d, e, f, g, h) = (A, B, C | d, e, f, g, h) -> (C', A, B | h', d', e, f, g): C' = a', d' = e', h' = old c
+#define HS_RV(A, B, C, d, e, f, g, h, kwv)                                                               \
+    do {                                                                                                \
+        uint64_t hk_ = h + (kwv);                                                                       \
+        uint64_t dhk_ = d + hk_;                                                                        \
+        HS_KEEP(hk_);                                                                                   \
+        HS_KEEP(dhk_);                                                                                  \
+        const uint64_t ch_ = ((f ^ g) & e) ^ g;                                                         \
+        const uint64_t s1_ = HS_S1(e);                                                                  \
+        uint64_t x_ = dhk_ + ch_;                                                                       \
+        uint64_t y_ = hk_ + ch_;                                                                        \
+        HS_KEEP(x_);                                                                                    \
+        HS_KEEP(y_);                                                                                    \
+        d = x_ + s1_;                                                                                   \
+        const __m128i t1_ = _mm_cvtsi64_si128((long long)(y_ + s1_));                                   \
+        const __m128i z_ = _mm_add_epi64(t1_, _mm_ternarylogic_epi64(A, B, C, 0xE8));                   \
+        h = (uint64_t)_mm_cvtsi128_si64(C);                                                             \
+        C = _mm_add_epi64(z_, _mm_ternarylogic_epi64(_mm_ror_epi64(A, 28), _mm_ror_epi64(A, 34), _mm_ror_epi64(A, 39), 0x96)); \
+    } while (0)
+
+__attribute__((target("avx512f,avx512vl,bmi2"))) static void blocks_avx512_va(uint64_t H[8], const uint8_t* p, size_t nblocks)
+{
+    const __m128i bswap = _mm_set_epi64x(0x08090a0b0c0d0e0fLL, 0x0001020304050607LL);
+    __m128i A = _mm_cvtsi64_si128((long long)H[0]), B = _mm_cvtsi64_si128((long long)H[1]), C = _mm_cvtsi64_si128((long long)H[2]);
+    uint64_t d = H[3], e = H[4], f = H[5], g = H[6], h = H[7];
+    alignas(16) uint64_t kw[16];
+    for (; nblocks; --nblocks, p += 128) {
+        __m128i X0 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 0)), bswap);
+        __m128i X1 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 16)), bswap);
+        __m128i X2 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 32)), bswap);
+        __m128i X3 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 48)), bswap);
+        __m128i X4 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 64)), bswap);
+        __m128i X5 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 80)), bswap);
+        __m128i X6 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 96)), bswap);
+        __m128i X7 = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 112)), bswap);
+        const __m128i sA = A, sB = B, sC = C;
+        const uint64_t sd = d, se = e, sf = f, sg = g, sh = h;
+        const uint64_t* K = K512;
+        // sixteen rounds a trip; the names rotate with period 3 (vector) and 5 (scalar), so a trip ends one name off
+        // in each: put them back (register moves)
+#define HS_UNROTATE()                                                                                   \
+    do {                                                                                                \
+        const __m128i tv_ = C; C = B; B = A; A = tv_;                                                   \
+        const uint64_t ts_ = h; h = g; g = f; f = e; e = d; d = ts_;                                    \
+    } while (0)
+        _Pragma("GCC unroll 1") for (int t = 0; t < 64; t += 16, K += 16)
+        {
+            HS_KW(X0, 0);
+            HS_RV(A, B, C, d, e, f, g, h, kw[0]);
+            HS_RV(C, A, B, h, d, e, f, g, kw[1]);
+            HS_SCHED(X0, X1, X4, X5, X7);
+            HS_KW(X1, 2);
+            HS_RV(B, C, A, g, h, d, e, f, kw[2]);
+            HS_RV(A, B, C, f, g, h, d, e, kw[3]);
+            HS_SCHED(X1, X2, X5, X6, X0);
+            HS_KW(X2, 4);
+            HS_RV(C, A, B, e, f, g, h, d, kw[4]);
+            HS_RV(B, C, A, d, e, f, g, h, kw[5]);
+            HS_SCHED(X2, X3, X6, X7, X1);
+            HS_KW(X3, 6);
+            HS_RV(A, B, C, h, d, e, f, g, kw[6]);
+            HS_RV(C, A, B, g, h, d, e, f, kw[7]);
+            HS_SCHED(X3, X4, X7, X0, X2);
+            HS_KW(X4, 8);
+            HS_RV(B, C, A, f, g, h, d, e, kw[8]);
+            HS_RV(A, B, C, e, f, g, h, d, kw[9]);
+            HS_SCHED(X4, X5, X0, X1, X3);
+            HS_KW(X5, 10);
+            HS_RV(C, A, B, d, e, f, g, h, kw[10]);
+            HS_RV(B, C, A, h, d, e, f, g, kw[11]);
+            HS_SCHED(X5, X6, X1, X2, X4);
+            HS_KW(X6, 12);
+            HS_RV(A, B, C, g, h, d, e, f, kw[12]);
+            HS_RV(C, A, B, f, g, h, d, e, kw[13]);
+            HS_SCHED(X6, X7, X2, X3, X5);
+            HS_KW(X7, 14);
+            HS_RV(B, C, A, e, f, g, h, d, kw[14]);
+            HS_RV(A, B, C, d, e, f, g, h, kw[15]);
+            HS_SCHED(X7, X0, X3, X4, X6);
+            HS_UNROTATE();
+        }
+        HS_KW(X0, 0);
+        HS_RV(A, B, C, d, e, f, g, h, kw[0]);
+        HS_RV(C, A, B, h, d, e, f, g, kw[1]);
+        HS_KW(X1, 2);
+        HS_RV(B, C, A, g, h, d, e, f, kw[2]);
+        HS_RV(A, B, C, f, g, h, d, e, kw[3]);
+        HS_KW(X2, 4);
+        HS_RV(C, A, B, e, f, g, h, d, kw[4]);
+        HS_RV(B, C, A, d, e, f, g, h, kw[5]);
+        HS_KW(X3, 6);
+        HS_RV(A, B, C, h, d, e, f, g, kw[6]);
+        HS_RV(C, A, B, g, h, d, e, f, kw[7]);
+        HS_KW(X4, 8);
+        HS_RV(B, C, A, f, g, h, d, e, kw[8]);
+        HS_RV(A, B, C, e, f, g, h, d, kw[9]);
+        HS_KW(X5, 10);
+        HS_RV(C, A, B, d, e, f, g, h, kw[10]);
+        HS_RV(B, C, A, h, d, e, f, g, kw[11]);
+        HS_KW(X6, 12);
+        HS_RV(A, B, C, g, h, d, e, f, kw[12]);
+        HS_RV(C, A, B, f, g, h, d, e, kw[13]);
+        HS_KW(X7, 14);
+        HS_RV(B, C, A, e, f, g, h, d, kw[14]);
+        HS_RV(A, B, C, d, e, f, g, h, kw[15]);
+        HS_UNROTATE();
+        A = _mm_add_epi64(A, sA); B = _mm_add_epi64(B, sB); C = _mm_add_epi64(C, sC);
+        d += sd; e += se; f += sf; g += sg; h += sh;
+    }
+    H[0] = (uint64_t)_mm_cvtsi128_si64(A); H[1] = (uint64_t)_mm_cvtsi128_si64(B); H[2] = (uint64_t)_mm_cvtsi128_si64(C);
+    H[3] = d; H[4] = e; H[5] = f; H[6] = g; H[7] = h;
+}
+
 __attribute__((target("avx2,bmi2"))) static void blocks_avx2(uint64_t H[8], const uint8_t* p, size_t nblocks)
 {
     HS_VEC_BODY(HS_S0V_AVX2, HS_S1V_AVX2)
 }
 
+#ifndef HS_AVX512_BEST
+#define HS_AVX512_BEST blocks_avx512
+#endif
 typedef void (*BlocksFn)(uint64_t*, const uint8_t*, size_t);
 static BlocksFn pick_blocks()
 {
     __builtin_cpu_init();
-    if (__builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2")) return blocks_avx512;
+    if (__builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2")) return HS_AVX512_BEST;
     if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")) return blocks_avx2;
     return blocks;
 }
@@ -223,12 +350,13 @@ static void (*const blocks_best)(uint64_t*, const uint8_t*, size_t) = blocks;
 #endif
 
 // which block function a build runs (tests: every spelling must agree)
-int host_sha512_variants() { return 3; }
+int host_sha512_variants() { return 4; }
 void host_sha512_blocks_variant(int v, uint64_t H[8], const uint8_t* p, size_t nblocks)
 {
 #if defined(__x86_64__)
     if (v == 1 && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")) return blocks_avx2(H, p, nblocks);
     if (v == 2 && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2")) return blocks_avx512(H, p, nblocks);
+    if (v == 3 && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("bmi2")) return blocks_avx512_va(H, p, nblocks);
 #endif
     blocks(H, p, nblocks);
 }

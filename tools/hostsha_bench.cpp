@@ -14,7 +14,7 @@ int main()
 {
     std::vector<uint8_t> buf(8 << 20);
     for (size_t i = 0; i < buf.size(); ++i) buf[i] = (uint8_t)(i * 2654435761u >> 13);
-    static const char* names[] = {"portable/bmi2", "avx2 schedule", "avx512vl schedule"};
+    static const char* names[] = {"portable/bmi2", "avx2 schedule", "avx512vl schedule", "avx512vl schedule + a-chain"};
     for (int v = 0; v < host_sha512_variants(); ++v) {
         uint64_t H[8];
         double best = 1e9;
@@ -25,7 +25,7 @@ int main()
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (dt < best) best = dt;
         }
-        printf("HS_ASSOC=%d %-18s %.3f GB/s  (H0 %016llx)\n", HS_ASSOC, names[v], buf.size() / best / 1e9, (unsigned long long)H[0]);
+        printf("HS_ASSOC=%d %-28s %.3f GB/s  (H0 %016llx)\n", HS_ASSOC, names[v], buf.size() / best / 1e9, (unsigned long long)H[0]);
     }
     return 0;
 }

@@ -99,3 +99,55 @@ def test_fused_build_pass_reads_once_and_matches_writehashes(built_lib, oracle, 
     for m in tf.getmembers():
         if m.isreg():
             assert tf.extractfile(m).read() == open(os.path.join(build, m.name[2:]), "rb").read(), m.name
+
+
+def test_tar_create_error_paths_leave_no_archive_and_a_usable_ctx(built_lib, oracle, tmp_path):
+    """tarCreate's error behaviour (clickdeb/deb.go:286-289, 331-339: the first Lstat/Open/Copy error ends the walk
+    and is returned) through the pipelined producer: an unreadable file in a later staging slot, an output that
+    cannot be written (the writer thread's ENOSPC), a name the ustar header cannot hold, an empty tree -- after each
+    failure no partial archive is left behind and the same ctx still produces a correct one."""
+    from snappy_amd import Context, _lib
+    rng = np.random.default_rng(5)
+    build, _ = trees.make_synthetic_tree(str(tmp_path), [int(x) for x in rng.integers(1000, 200000, size=40)])
+    os.makedirs(os.path.join(build, "DEBIAN"))
+    out = str(tmp_path / "data.tar.gz")
+    with Context(staging_bytes=1 << 20) as c:
+        good_yaml, _ = c.tar_create(out, build, build + "/DEBIAN", with_hashes=True)
+        assert good_yaml == oracle.hashes_yaml(build, out)
+        os.unlink(out)
+        # 1. a file that cannot be opened (skipped when running as root, who can read anything)
+        victim = sorted(p for p in (os.path.join(dp, f) for dp, _, fs in os.walk(build) for f in fs))[-1]
+        os.chmod(victim, 0)
+        if os.geteuid() != 0:
+            with pytest.raises(_lib.SnaphashError) as ei:
+                c.tar_create(out, build, build + "/DEBIAN", with_hashes=True)
+            assert ei.value.code == _lib.EIO and os.path.basename(victim) in str(ei.value) and not os.path.exists(out)
+        os.chmod(victim, 0o644)
+        # 2. the output cannot take the bytes: the writer thread's error comes back, with errno's text
+        full = str(tmp_path / "full.tar.gz")
+        os.symlink("/dev/full", full)
+        with pytest.raises(_lib.SnaphashError) as ei:
+            c.tar_create(full, build, build + "/DEBIAN", with_hashes=True)
+        assert ei.value.code == _lib.EIO and "No space left" in str(ei.value)
+        with pytest.raises(_lib.SnaphashError) as ei:
+            c.tar_create(str(tmp_path / "no-such-dir" / "x.tar.gz"), build)
+        assert ei.value.code == _lib.EIO
+        # 3. a member name that fits neither the name field nor the prefix split
+        long_dir = os.path.join(build, "n" * 120)
+        os.makedirs(long_dir)
+        open(os.path.join(long_dir, "m" * 120), "wb").write(b"x")
+        with pytest.raises(_lib.SnaphashError) as ei:
+            c.tar_create(out, build, build + "/DEBIAN")
+        assert ei.value.code == _lib.ENAME and not os.path.exists(out)
+        import shutil
+        shutil.rmtree(long_dir)
+        # ... and the ctx is as good as new
+        y2, dig = c.tar_create(out, build, build + "/DEBIAN", with_hashes=True)
+        assert y2 == oracle.hashes_yaml(build, out) and hashlib.sha512(open(out, "rb").read()).digest() == dig
+        # 4. an empty tree: two zero records, `files: []`
+        empty = str(tmp_path / "empty")
+        os.makedirs(empty)
+        out2 = str(tmp_path / "empty.tar.gz")
+        y3, dig3 = c.tar_create(out2, empty, empty + "/DEBIAN", with_hashes=True)
+        assert gzip.decompress(open(out2, "rb").read()) == bytes(1024)
+        assert y3 == oracle.hashes_yaml(empty, out2) and b"files: []" in y3

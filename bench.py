@@ -22,11 +22,14 @@ Prints ONE JSON line on rank 0:
                 events on the launch stream (library stats)
   end_to_end    N = 1 only: host buffers -> digests (snaphash_sha512_buffers) and
                 on-disk tree -> hashes.yaml (snaphash_tree), the latter compared
-                byte for byte with the oracle's hashes.yaml
+                byte for byte with the oracle's hashes.yaml; and `build`: Build's
+                data step fused (tar + GPU DEFLATE + archive digest + hashes.yaml)
+                on a 1 GiB text tree
   cpu_baseline  the oracle (C restatement of the reference's serial loop) timed
                 on this box's host cores over a bounded sample of the same tree
 """
 import argparse
+import hashlib
 import json
 import os
 import shutil
@@ -209,6 +212,56 @@ def e2e_tree(ctx, host, offsets, lens, nfiles, cpu_seconds):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def e2e_build(ctx, total_mib=1024):
+    """Rows f2 + f3: `Build`'s data step in one pass -- data.tar.gz (GPU DEFLATE) + archive digest + per-file SHA-512
+    + hashes.yaml, every file read once -- on a compressible tree (Zipf-word text, 1 MiB files); the archive is read
+    back with tarfile and the yaml compared with the oracle's over the tree and the archive just written."""
+    import tarfile
+    from oracle import oracle
+    from snappy_amd import synthetic
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(prefix="snaphash_build_", dir=base)
+    try:
+        build = os.path.join(tmp, "build")
+        os.makedirs(os.path.join(build, "DEBIAN"))
+        rng = np.random.default_rng(5)
+        words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(2000)]
+        block = b" ".join(words[int(i)] for i in rng.zipf(1.3, size=(4 << 20) // 5 + 16) % 2000)[:4 << 20]
+        for i in range(total_mib):
+            p = os.path.join(build, synthetic.file_name(i))
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            off = int(rng.integers(0, len(block) - 1))
+            with open(p, "wb") as f:
+                f.write((block[off:] + block)[:1 << 20])
+        out = os.path.join(tmp, "data.tar.gz")
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y, dig = ctx.tar_create(out, build, build + "/DEBIAN", with_hashes=True)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, ctx.stats(), ctx.targz_stats())
+        dt, st, zs = best
+        if hashlib.sha512(open(out, "rb").read()).digest() != dig or oracle.hashes_yaml(build, out) != y:
+            raise SystemExit("PARITY FAILURE: the fused build pass disagrees with hashlib / the oracle")
+        tf = tarfile.open(out, "r:gz")
+        for k, m in enumerate(tf):
+            if k >= 24:
+                break
+            if m.isreg() and tf.extractfile(m).read() != open(os.path.join(build, m.name[2:]), "rb").read():
+                raise SystemExit("PARITY FAILURE: archive member %s differs from the file" % m.name)
+        return {"what": "on-disk tree (tmpfs, %d x 1 MiB Zipf-word text) -> snaphash_tar_create: tar + GPU DEFLATE + archive "
+                        "SHA-512 + per-file SHA-512 + hashes.yaml, one read of every file" % total_mib,
+                "tar_bytes": int(zs["tar_bytes"]), "gz_bytes": int(zs["gz_bytes"]), "ratio": round(zs["gz_bytes"] / zs["tar_bytes"], 4),
+                "ms": round(dt * 1e3, 1), "GiBps_of_tree": round(zs["tar_bytes"] / 2**30 / dt, 2),
+                "deflate_kernel_ms": round(zs["deflate_ms"], 1), "sha512_kernel_ms": round(st["kernel_ms"], 1),
+                "bound": "the serial SHA-512 of the archive on one host core (DESIGN.md sec. 9)",
+                "parity": "archive inflates to the tree (tarfile); archive digest = hashlib; hashes.yaml byte-identical to the oracle's",
+                "best_of": 3}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     import torch
@@ -322,7 +375,6 @@ def main():
     digests = job["digests"]
     parity = None
     if rank == 0:
-        import hashlib
         rng = np.random.default_rng(1)
         sample = sorted(set([0, len(sizes) - 1] + [int(x) for x in rng.integers(0, len(sizes), size=14)]))
         sample = [i for i in sample if sizes[i] <= (64 << 20)] or [int(np.argmin(sizes))]
@@ -348,6 +400,7 @@ def main():
             if mode == "full":
                 end_to_end["tree"], cpu = e2e_tree(ectx, host, job["my_off"], job["my_lens"], args.e2e_files,
                                                    args.cpu_seconds)
+                end_to_end["build"] = e2e_build(ectx)
             ectx.close()
             del host
         if args.cpu_seconds > 0:

@@ -51,7 +51,7 @@ void host_sha512_resume(HostSha& s, const uint64_t H[8], uint64_t total_prev)
 #define HS_s0(x) (HS_ROTR(x, 1) ^ HS_ROTR(x, 8) ^ ((x) >> 7))
 #define HS_s1(x) (HS_ROTR(x, 19) ^ HS_ROTR(x, 61) ^ ((x) >> 6))
 // HS_ASSOC picks how a round is associated (tools/hostsha_bench.cpp measures them; EPYC 9575F, AVX-512VL schedule:
-// 0/1 1.34 GB/s, 2 1.42, 3 1.43 -- hashlib/OpenSSL on the same core: 1.33)
+// 0/1 1.34 GB/s, 2 1.42, 3 1.43 -- hashlib/OpenSSL on the same core: 1.45)
 #ifndef HS_ASSOC
 #define HS_ASSOC 3
 #endif

@@ -7,18 +7,19 @@
 // must return exactly the tar stream -- not the bytes Go's compressor would emit.
 //
 // Parallel axis: the stream is cut into 16 KiB chunks; one wave64 compresses one chunk on its
-// own (hash table in LDS, seeded with the previous chunk so that matches reach 32 KiB back) into a dynamic- or
-// fixed-Huffman block (two passes with the same parse: count, build the codes, emit), ends
+// own (four-way hash buckets in LDS, seeded with the previous chunk so that matches reach 32 KiB back) into a
+// dynamic- or fixed-Huffman block (parse and count, build the codes, emit the remembered tokens), ends
 // it with an empty stored block so that the chunk's output is byte aligned (what zlib's
 // Z_SYNC_FLUSH does), and the chunk outputs are concatenated by a second kernel.  A chunk
 // that does not shrink is emitted as a stored block.  Per tile of 64 input positions
-// (lane = position): hash 4 bytes, look the candidate up, extend the match, a scalar greedy
-// parse with one-byte lazy evaluation over the wave's match mask, then every token-start lane encodes its own token and a
-// prefix sum of the bit lengths places it in the LDS bit buffer.
+// (lane = position): hash 4 bytes, look up to four candidates up, extend the matches, a scalar greedy
+// parse with one-byte lazy evaluation over the wave's match mask; in the second pass every token-start lane encodes
+// its own token and a prefix sum of the bit lengths places it in the LDS bit buffer.
 //
-// This kernel is integer/LDS work with data-dependent control flow: no MFMA.  Bound: each input
-// byte is read ~2x (position + candidate, L2-resident within a chunk) and <= 1.13 B written per
-// byte; the measured rate (profiles/) is far below HBM -- the parse loop, not memory, bounds it.
+// This kernel is integer/LDS work with data-dependent control flow: no MFMA.  Algorithmic bytes: 1 read and
+// <= 1.13 written per input byte; the token scratch adds 4 B out and back per byte.  The measured rate (profiles/)
+// is far below HBM -- instruction issue and LDS latency bound it, and the pass it serves is bound elsewhere (the
+// serial digest of the archive), see DESIGN.md sec. 9.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -90,10 +91,11 @@ __device__ __forceinline__ void put_bits(uint32_t* ob, uint32_t at, uint32_t flu
 }
 
 // One wave per chunk, four waves (chunks) per workgroup.  in: the stream (readable up to n_in + 8);
-// slots: nchunks * kDeflateSlot bytes; sizes[c]: bytes chunk c produced.
-// Two passes over the chunk with the identical parse: pass 0 counts symbols (and the cost of a fixed-Huffman
-// block), one lane builds the dynamic codes (deflate_core.h: the host model runs the same routines), pass 1
-// emits a dynamic or a fixed block, whichever is smaller; a chunk that does not shrink is stored.
+// slots: nchunks * kDeflateSlot bytes; sizes[c]: bytes chunk c produced; toks: one scratch word per input byte.
+// Pass 1 parses the chunk, counts symbols (and prices a fixed-Huffman block) and writes its tokens to `toks`; one
+// lane builds the dynamic codes and the block header (deflate_core.h: the host model runs the same routines);
+// pass 2 re-reads the tokens (each lane its own) and emits a dynamic or a fixed block, whichever is smaller; a
+// chunk that does not shrink is stored.
 __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __restrict__ in, uint64_t n_in,
                                                              uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
                                                              uint32_t* __restrict__ toks, uint32_t nchunks)

@@ -222,7 +222,11 @@ __device__ __forceinline__ void schedule_span(uint64_t w[16], uint64_t* __restri
 #pragma unroll
     for (int t = T0; t < T1; ++t) {
         if (t >= 16) w[t & 15] += small_sigma1(w[(t + 14) & 15]) + w[(t + 9) & 15] + small_sigma0(w[(t + 1) & 15]);
+#if defined(SNAPHASH_EXPERIMENT_NO_KW_STORE) // timing experiment only (wrong digests): the schedule is computed, never stored
+        { uint64_t v_ = w[t & 15] + K512[t]; asm volatile("" ::"v"(v_)); (void)row; }
+#else
         row[t] = w[t & 15] + K512[t];
+#endif
     }
 }
 
@@ -344,9 +348,11 @@ __device__ __forceinline__ void split_helper_wave(SplitShared& sh, uint32_t hk, 
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const uint32_t p = (b + 2u) * 8u + piece;
+                [[maybe_unused]] const uint32_t p = (b + 2u) * 8u + piece;
                 pre[i] = make_uint4(0, 0, 0, 0);
+#if !defined(SNAPHASH_EXPERIMENT_NO_FETCH) // timing experiment only (wrong digests): no global loads in the helpers
                 if (p < tnp[i]) pre[i] = load_u4(tptr[i] + (uint64_t)(b + 2u) * 128u);
+#endif
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

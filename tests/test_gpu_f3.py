@@ -151,3 +151,51 @@ def test_tar_create_error_paths_leave_no_archive_and_a_usable_ctx(built_lib, ora
         y3, dig3 = c.tar_create(out2, empty, empty + "/DEBIAN", with_hashes=True)
         assert gzip.decompress(open(out2, "rb").read()) == bytes(1024)
         assert y3 == oracle.hashes_yaml(empty, out2) and b"files: []" in y3
+
+
+def test_tar_create_slot_boundaries_random_trees(built_lib, oracle, tmp_path):
+    """Slot-boundary logic of the producer under small, odd staging sizes: headers, file bodies, record padding and
+    the two closing zero records all get to straddle a slot somewhere in 24 random trees x 3 staging sizes; every
+    archive must inflate to the tar stream the host model lays out, and every fused hashes.yaml must be the oracle's."""
+    import ctypes
+    import shutil
+    from snappy_amd import Context
+    rng = np.random.default_rng(21)
+    so = str(tmp_path / "libf3host.so")
+    import subprocess
+    from conftest import ROOT
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "f3_host_harness.cpp")])
+    L = ctypes.CDLL(so)
+    L.f3_tar_stream.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.f3_free.argtypes = [ctypes.c_void_p]
+    ctxs = [Context(staging_bytes=s) for s in (1 << 16, (1 << 16) + (1 << 14), 3 << 16)]
+    try:
+        for it in range(24):
+            build = str(tmp_path / ("t%d" % it))
+            os.makedirs(os.path.join(build, "DEBIAN"))
+            nfiles = int(rng.integers(0, 14))
+            for k in range(nfiles):
+                d = os.path.join(build, "d%d" % int(rng.integers(0, 3)))
+                os.makedirs(d, exist_ok=True)
+                # sizes cluster around the record and slot sizes
+                size = int(rng.choice([0, 1, 511, 512, 513, 16383, 16384, 65536 - 512, 65536, 65537, int(rng.integers(0, 200000))]))
+                data = rng.integers(0, 256, size=size, dtype=np.uint8).tobytes() if k % 2 else (b"abcdefgh" * (size // 8 + 1))[:size]
+                with open(os.path.join(d, "f%02d" % k), "wb") as f:
+                    f.write(data)
+            if it % 3 == 0:
+                os.symlink("f00", os.path.join(build, "link"))
+            p, n = ctypes.c_void_p(), ctypes.c_size_t()
+            assert L.f3_tar_stream(build.encode(), (build + "/DEBIAN").encode(), ctypes.byref(p), ctypes.byref(n)) == 0
+            want_tar = ctypes.string_at(p.value, n.value)
+            L.f3_free(p)
+            for c in ctxs:
+                out = str(tmp_path / "o.tar.gz")
+                y, dig = c.tar_create(out, build, build + "/DEBIAN", with_hashes=True)
+                raw = open(out, "rb").read()
+                assert gzip.decompress(raw) == want_tar, (it, nfiles)
+                assert hashlib.sha512(raw).digest() == dig
+                assert y == oracle.hashes_yaml(build, out), (it, nfiles)
+            shutil.rmtree(build)
+    finally:
+        for c in ctxs:
+            c.close()

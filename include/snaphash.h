@@ -121,6 +121,10 @@ typedef struct snaphash_stats_ex { /* of the most recent hashing call on the ctx
 } snaphash_stats_ex;
 
 /* ---- lifetime -------------------------------------------------------------- */
+/* cfg == NULL: the calling thread's current device, defaults throughout -- unless the environment says otherwise
+ * (the reference's build has neither config file nor flags for this): SNAPHASH_DEVICES = "all" or
+ * "0,1,..." names the engines, SNAPHASH_HOST_THREADS = N turns hybrid scheduling on.  A non-NULL cfg is taken as
+ * it is; the environment is not consulted. */
 int snaphash_init(const snaphash_config *cfg /* may be NULL */, snaphash_ctx **out);
 void snaphash_destroy(snaphash_ctx *ctx);
 int snaphash_abi_version(void);

@@ -13,6 +13,7 @@
  * options: -d DEV[,DEV...]  engines (default: the current device; -1 = all visible)
  *          -t N             hybrid scheduling: oversize streams finish on N host threads
  *          -s               print the statistics of the call on stderr
+ * without -d/-t the environment may name them: SNAPHASH_DEVICES=all|0,1,...  SNAPHASH_HOST_THREADS=N
  * Pure C against include/snaphash.h: it is also the smallest example of the ABI. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,7 +23,7 @@
 
 static int die(snaphash_ctx *c, int rc, const char *what)
 {
-    fprintf(stderr, "snaphash: %s: %s (%s)\n", what, snaphash_strerror(rc), c ? snaphash_last_error(c) : "");
+    fprintf(stderr, "snaphash: %s: %s (%s)\n", what, snaphash_strerror(rc), snaphash_last_error(c)); /* c == NULL: why snaphash_init failed */
     return rc == SNAPHASH_EMISMATCH ? 1 : 2;
 }
 
@@ -74,7 +75,8 @@ int main(int argc, char **argv)
     argv += a - 1;
     if (argc < 3) return usage();
     snaphash_ctx *c = NULL;
-    int rc = snaphash_init(&cfg, &c);
+    /* no engine option given: NULL config, so that SNAPHASH_DEVICES / SNAPHASH_HOST_THREADS apply (snaphash.h) */
+    int rc = snaphash_init((cfg.n_devices || cfg.host_threads) ? &cfg : NULL, &c);
     if (rc) return die(NULL, rc, "snaphash_init");
     int ret = 0;
     if (!strcmp(argv[1], "hash")) {

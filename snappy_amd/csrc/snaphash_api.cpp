@@ -937,6 +937,22 @@ int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
             for (uint32_t k = 0; k < cfg->n_devices; ++k) devs.push_back(cfg->devices[k]);
         }
         if (cfg->stream && devs.size() > 1) return init_fail(SNAPHASH_EINVAL, "a caller stream needs a single-device ctx");
+    } else if (!cfg && getenv("SNAPHASH_DEVICES")) {
+        // A caller that passes no config (the cgo shim's default) can be steered from the environment, as the
+        // reference's build has no config file: SNAPHASH_DEVICES = "all" or "0,1,...".
+        const char* p = getenv("SNAPHASH_DEVICES");
+        if (!strcmp(p, "all") || !strcmp(p, "-1")) {
+            for (int d = 0; d < ndev; ++d) devs.push_back(d);
+        } else {
+            while (*p) {
+                char* end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p || (*end && *end != ',')) return init_fail(SNAPHASH_EINVAL, "SNAPHASH_DEVICES: expected \"all\" or a comma-separated list of ordinals");
+                devs.push_back((int)d);
+                p = *end ? end + 1 : end;
+            }
+            if (devs.empty()) return init_fail(SNAPHASH_EINVAL, "SNAPHASH_DEVICES is empty");
+        }
     } else {
         int dev = v1 ? cfg->device : -1;
         if (dev < 0 && (e = hipGetDevice(&dev)) != hipSuccess) return init_fail(SNAPHASH_EDEVICE, "hipGetDevice", e);
@@ -946,6 +962,8 @@ int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
     std::unique_ptr<snaphash_ctx> x(new (std::nothrow) snaphash_ctx());
     if (!x) return SNAPHASH_ENOMEM;
     if (v2) { x->host_threads = std::min<uint32_t>(cfg->host_threads, 256); x->flags = cfg->flags; }
+    if (!cfg && getenv("SNAPHASH_HOST_THREADS")) // likewise: hybrid scheduling for a ctx created without a config
+        x->host_threads = (uint32_t)std::min<unsigned long>(strtoul(getenv("SNAPHASH_HOST_THREADS"), nullptr, 10), 256);
     if (x->host_threads) x->host_rate = measure_host_rate();
     for (size_t k = 0; k < devs.size(); ++k) {
         const int dev = devs[k];

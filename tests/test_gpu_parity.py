@@ -415,6 +415,15 @@ def test_cli_build_gzip_cmp(built_lib, oracle, tmp_path):
     (da / "changed").write_bytes(b"1"); (db / "changed").write_bytes(b"2")
     r = subprocess.run([cli, "dirupdated", str(da), str(db), "pfx_"], stdout=subprocess.PIPE, timeout=120)
     assert r.returncode == 0 and r.stdout.decode().split() == ["pfx_changed"]
+    # a ctx created without a config takes its engines from the environment (snaphash_init(NULL), include/snaphash.h)
+    big = str(tmp_path / "big.tar.gz")
+    oracle.fill_synthetic(48 << 20, 7).tofile(big)
+    env = dict(os.environ, SNAPHASH_HOST_THREADS="2", SNAPHASH_DEVICES="0")
+    r = subprocess.run([cli, "-s", "tree", build, big], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+    assert r.returncode == 0 and r.stdout == oracle.hashes_yaml(build, big)
+    assert ("host threads hashed %d B" % (48 << 20)) in r.stderr.decode()
+    r = subprocess.run([cli, "tree", build, big], stderr=subprocess.PIPE, timeout=120, env=dict(os.environ, SNAPHASH_DEVICES="zero"))
+    assert r.returncode == 2 and b"SNAPHASH_DEVICES" in r.stderr
 
 
 def test_config_c2_on_disk_tree_scaled(built_lib, oracle):

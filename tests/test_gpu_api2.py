@@ -230,3 +230,57 @@ def test_large_tree_third_opinion_pyyaml_hashlib(built_lib, tmp_path):
     walk(build, "")
     assert len(doc["files"]) == len(want) == 1200 + 12 + 1
     assert doc["files"] == want
+
+
+def test_distinct_contexts_on_concurrent_threads(built_lib, oracle, tmp_path):
+    """The threading contract of include/snaphash.h: a ctx serves one call at a time, DISTINCT ctxs
+    may be used concurrently.  Four threads, each with its own ctx, run different entry points at once (tree over
+    files, host buffers, the fused tar.gz producer, gzip of a buffer); every result is checked against the oracle /
+    hashlib / gzip.  ctypes releases the GIL for the duration of each call, so the calls really overlap."""
+    import gzip
+    import hashlib
+    import threading
+    from snappy_amd import Context
+    rng = np.random.default_rng(9)
+    build, tar = trees.make_synthetic_tree(str(tmp_path), [int(x) for x in rng.integers(1, 400000, size=80)])
+    os.makedirs(os.path.join(build, "DEBIAN"), exist_ok=True)
+    want_yaml = oracle.hashes_yaml(build, tar)
+    bufs = [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in rng.integers(0, 300000, size=120)]
+    want_digs = [hashlib.sha512(b).digest() for b in bufs]
+    text = (b"concurrency is not parallelism " * 40000)[: 1 << 20]
+    errors = []
+
+    def guard(fn):
+        def run():
+            try:
+                for _ in range(3):
+                    fn()
+            except BaseException as e:  # noqa: BLE001 -- report from the main thread
+                errors.append(repr(e))
+        return run
+
+    def t_tree():
+        with Context(staging_bytes=1 << 20) as c:
+            assert c.tree(build, tar) == want_yaml
+
+    def t_buffers():
+        with Context(staging_bytes=1 << 20) as c:
+            assert list(c.sha512_buffers(bufs)) == want_digs
+
+    def t_build():
+        out = str(tmp_path / ("o%d.tar.gz" % threading.get_ident()))
+        with Context(staging_bytes=1 << 20) as c:
+            y, dig = c.tar_create(out, build, build + "/DEBIAN", with_hashes=True)
+            assert hashlib.sha512(open(out, "rb").read()).digest() == dig and y == oracle.hashes_yaml(build, out)
+
+    def t_gzip():
+        with Context(staging_bytes=1 << 18) as c:
+            assert gzip.decompress(c.gzip_buffer(text)) == text
+
+    th = [threading.Thread(target=guard(f)) for f in (t_tree, t_buffers, t_build, t_gzip)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in th)

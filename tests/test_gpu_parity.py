@@ -187,6 +187,44 @@ def test_device_entry_point_vs_oracle(ctx, oracle):
     assert ctx.stats()["bytes_hashed"] == int(lens.sum())
 
 
+def test_kernels_write_nothing_but_their_outputs(ctx, oracle):
+    """No GPU sanitizer on this pool (rely on canary-padded buffers): the digest matrix and the file
+    bytes sit inside larger allocations filled with a sentinel; after a ragged batch -- every kernel variant of the
+    ctx fixture -- the digests are right, the sentinels around them and the input bytes are untouched.  Likewise
+    for the range-comparison kernel's result vector."""
+    torch = _torch()
+    from snappy_amd import synthetic
+    rng = np.random.default_rng(31)
+    lens = np.concatenate([rng.integers(0, 70000, size=200), [0, 1, 111, 112, 127, 128, 129, 1 << 17]]).astype(np.uint64)
+    off, total = synthetic.pack_offsets(lens, 16)
+    pad = 4096
+    host = np.full(total + 2 * pad, 0xA5, dtype=np.uint8)
+    host[pad:pad + total] = rng.integers(0, 256, size=total, dtype=np.uint8)
+    dev = torch.from_numpy(host).cuda()
+    n = len(lens)
+    outbuf = torch.full((pad + n * 64 + pad,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.sha512_device(dev.data_ptr() + pad, off, lens, outbuf.data_ptr() + pad)
+    ctx.sync()
+    o = outbuf.cpu().numpy()
+    assert (o[:pad] == 0x5A).all() and (o[pad + n * 64:] == 0x5A).all()
+    assert (o[pad:pad + n * 64].reshape(n, 64) == oracle.sha512_batch(host[pad:], off, lens)).all()
+    assert (dev.cpu().numpy() == host).all()  # inputs (and the bytes between and around them) are read-only
+    # the comparison kernel: d_equal is n bytes, nothing else
+    eq = torch.full((pad + n + pad,), 0x5A, dtype=torch.uint8, device="cuda")
+    dev2 = dev.clone()
+    flip = int(off[5]) + pad + 3
+    dev2[flip] = dev2[flip] ^ 0xFF
+    torch.cuda.synchronize()
+    ctx.ranges_equal_device(dev.data_ptr() + pad, off, dev2.data_ptr() + pad, off, lens, eq.data_ptr() + pad)
+    ctx.sync()
+    e = eq.cpu().numpy()
+    assert (e[:pad] == 0x5A).all() and (e[pad + n:] == 0x5A).all()
+    want = np.ones(n, dtype=np.uint8)
+    want[5] = 0
+    assert (e[pad:pad + n] == want).all()
+
+
 def test_synthetic_fill_matches_generator(ctx, oracle):
     torch = _torch()
     from snappy_amd import synthetic

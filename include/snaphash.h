@@ -12,7 +12,9 @@
  *   snappy/click.go:330-338,970  writeHashesFile (install side: where Verify hooks in)
  *
  * Conventions
- *   - extern "C", plain pointers and sizes; no C++ or torch types cross the line.
+ *   - extern "C", plain pointers and sizes; no C++ or torch types cross the line, and no
+ *     C++ exception either: an allocation or thread-creation failure inside a call comes
+ *     back as SNAPHASH_ENOMEM.
  *   - Return 0 on success, a negative SNAPHASH_E* code otherwise.  As in the
  *     reference (build.go:242-244) the first per-file error fails the whole
  *     batch and no output may be trusted.

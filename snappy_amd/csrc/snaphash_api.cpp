@@ -880,9 +880,11 @@ int snaphash_abi_version(void) { return SNAPHASH_ABI_VERSION; }
 static thread_local std::string g_init_error; // why the last snaphash_init on this thread failed
 
 static int init_fail(int code, const std::string& what, hipError_t e = hipSuccess)
-{
+try {
     g_init_error = what + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string());
     return code;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 static void destroy_dev(DevCtx* c)
@@ -919,7 +921,7 @@ static void destroy_dev(DevCtx* c)
 }
 
 int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
-{
+try {
     if (!out) return SNAPHASH_EINVAL;
     *out = nullptr;
     g_init_error.clear();
@@ -1004,6 +1006,8 @@ int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
     }
     *out = x.release();
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 void snaphash_destroy(snaphash_ctx* x)
@@ -1029,16 +1033,18 @@ void snaphash_destroy(snaphash_ctx* x)
     const double t_top0_ = now_ms()
 
 int snaphash_sha512_files(snaphash_ctx* x, const char* const* paths, size_t n, uint8_t* digests, int32_t* status)
-{
+try {
     if (!x || (n && (!paths || !digests))) return fail(x, SNAPHASH_EINVAL, "bad argument");
     TOP_ENTER(x);
     int rc = hash_paths(x, paths, n, nullptr, digests, status);
     end_top(x, t_top0_);
     return rc;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_sha512_buffers(snaphash_ctx* x, const void* const* bufs, const uint64_t* lens, size_t n, uint8_t* digests)
-{
+try {
     if (!x || (n && (!bufs || !lens || !digests))) return fail(x, SNAPHASH_EINVAL, "bad argument");
     TOP_ENTER(x);
     std::vector<Source> src(n);
@@ -1050,11 +1056,13 @@ int snaphash_sha512_buffers(snaphash_ctx* x, const void* const* bufs, const uint
     int rc = hash_sources_top(x, src, digests, nullptr);
     end_top(x, t_top0_);
     return rc;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_sha512_device(snaphash_ctx* x, const void* d_base, const uint64_t* offsets, const uint64_t* lens,
                            size_t n, void* d_digests)
-{
+try {
     if (!x || (n && (!d_base || !offsets || !lens || !d_digests))) return fail(x, SNAPHASH_EINVAL, "bad argument");
     if (((uintptr_t)d_base & 15) != 0) return fail(x, SNAPHASH_EINVAL, "d_base must be 16-byte aligned");
     if (n > 0xffffffffull) return fail(x, SNAPHASH_EINVAL, "too many streams");
@@ -1084,10 +1092,12 @@ int snaphash_sha512_device(snaphash_ctx* x, const void* d_base, const uint64_t* 
     }
     c->stats.streams = n;
     return lift(x, c, launch_jobs(c, c->h_jobs, c->d_jobs, n, (uint8_t*)d_digests));
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_sync(snaphash_ctx* x)
-{
+try {
     if (!x) return SNAPHASH_EINVAL;
     for (auto& d : x->dev) {
         HIP_TRY(d.get(), hipSetDevice(d->device));
@@ -1098,6 +1108,8 @@ int snaphash_sync(snaphash_ctx* x)
     merge_stats(x);
     if (x->stats.wall_ms == 0) x->stats.wall_ms = wall;
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 // ---- the pass -----------------------------------------------------------------------
@@ -1145,7 +1157,7 @@ static int write_yaml_file(snaphash_ctx* x, const char* build_dir, const std::st
 
 int snaphash_tree_ex(snaphash_ctx* x, const char* build_dir, const char* data_tar, const uint8_t* archive_digest,
                      int write_file, char** yaml_out, size_t* yaml_len)
-{
+try {
     if (!x || !build_dir || (!data_tar && !archive_digest) || (!write_file && !yaml_out)) return fail(x, SNAPHASH_EINVAL, "bad argument");
     if (yaml_out) *yaml_out = nullptr;
     if (write_file) {
@@ -1167,18 +1179,24 @@ int snaphash_tree_ex(snaphash_ctx* x, const char* build_dir, const char* data_ta
     }
     if (yaml_len) *yaml_len = y.size();
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_tree(snaphash_ctx* x, const char* build_dir, const char* data_tar, char** yaml_out, size_t* yaml_len)
-{
+try {
     if (!x || !build_dir || !data_tar || !yaml_out) return fail(x, SNAPHASH_EINVAL, "bad argument");
     return snaphash_tree_ex(x, build_dir, data_tar, nullptr, 0, yaml_out, yaml_len);
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_write_hashes(snaphash_ctx* x, const char* build_dir, const char* data_tar)
-{
+try {
     if (!x || !build_dir || !data_tar) return fail(x, SNAPHASH_EINVAL, "bad argument");
     return snaphash_tree_ex(x, build_dir, data_tar, nullptr, 1, nullptr, nullptr);
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 static int mismatch(snaphash_ctx* c, snaphash_mismatch* m, int kind, const std::string& name)
@@ -1195,7 +1213,7 @@ static int mismatch(snaphash_ctx* c, snaphash_mismatch* m, int kind, const std::
 
 int snaphash_verify(snaphash_ctx* x, const char* inst_dir, const char* data_tar, const char* yaml, size_t yaml_len,
                     snaphash_mismatch* first)
-{
+try {
     if (!x || !inst_dir || !yaml) return fail(x, SNAPHASH_EINVAL, "bad argument");
     TOP_ENTER(x);
     ParsedHashes ph;
@@ -1251,6 +1269,8 @@ int snaphash_verify(snaphash_ctx* x, const char* inst_dir, const char* data_tar,
         }
     }
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 void snaphash_free(void* p) { free(p); }
@@ -1372,7 +1392,7 @@ int batch_place(snaphash_batch* b, size_t s, const uint8_t* p1, size_t n1, const
 extern "C" {
 
 int snaphash_batch_begin(snaphash_ctx* x, size_t n_streams, snaphash_batch** out)
-{
+try {
     if (!x || !out) return fail(x, SNAPHASH_EINVAL, "bad argument");
     *out = nullptr;
     if (x->dev.size() != 1) return fail(x, SNAPHASH_EINVAL, "streaming batches need a single-device ctx");
@@ -1394,10 +1414,12 @@ int snaphash_batch_begin(snaphash_ctx* x, size_t n_streams, snaphash_batch** out
     x->open_batch = b;
     *out = b;
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_batch_append(snaphash_batch* b, size_t stream, const void* data, size_t n)
-{
+try {
     if (!b) return SNAPHASH_EINVAL;
     if (b->failed) return fail(b->x, SNAPHASH_EINVAL, "the batch has failed");
     if (stream >= b->n || (!data && n) || b->st[stream].ended) return fail(b->x, SNAPHASH_EINVAL, "bad stream or buffer");
@@ -1417,10 +1439,12 @@ int snaphash_batch_append(snaphash_batch* b, size_t stream, const void* data, si
     st.ntail = (uint32_t)(n - from_data);
     if (st.ntail) memcpy(st.tail, p + from_data, st.ntail);
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_batch_end(snaphash_batch* b, size_t stream)
-{
+try {
     if (!b) return SNAPHASH_EINVAL;
     if (b->failed) return fail(b->x, SNAPHASH_EINVAL, "the batch has failed");
     if (stream >= b->n) return fail(b->x, SNAPHASH_EINVAL, "bad stream");
@@ -1432,10 +1456,12 @@ int snaphash_batch_end(snaphash_batch* b, size_t stream)
     if (rc) { b->failed = true; return lift(b->x, b->c, rc); }
     st.ntail = 0;
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_batch_finish(snaphash_batch* b, uint8_t* digests)
-{
+try {
     if (!b) return SNAPHASH_EINVAL;
     snaphash_ctx* x = b->x;
     DevCtx* c = b->c;
@@ -1455,6 +1481,8 @@ int snaphash_batch_finish(snaphash_batch* b, uint8_t* digests)
     x->open_batch = nullptr;
     delete b;
     return rc;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 void snaphash_batch_abort(snaphash_batch* b)
@@ -1698,7 +1726,7 @@ int files_equal_impl(DevCtx* c, const char* const* a, const char* const* b, size
 extern "C" {
 
 int snaphash_files_equal(snaphash_ctx* x, const char* const* a, const char* const* b, size_t n, uint8_t* equal)
-{
+try {
     if (!x || (n && (!a || !b || !equal))) return fail(x, SNAPHASH_EINVAL, "bad argument");
     TOP_ENTER(x);
     DevCtx* c = x->d0(); // the comparison scan runs on the ctx's first engine
@@ -1707,11 +1735,13 @@ int snaphash_files_equal(snaphash_ctx* x, const char* const* a, const char* cons
     merge_stats(x);
     end_top(x, t_top0_);
     return rc;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_ranges_equal_device(snaphash_ctx* x, const void* d_a, const uint64_t* off_a, const void* d_b,
                                  const uint64_t* off_b, const uint64_t* lens, size_t n, void* d_equal)
-{
+try {
     if (!x || (n && (!d_a || !d_b || !off_a || !off_b || !lens || !d_equal))) return fail(x, SNAPHASH_EINVAL, "bad argument");
     if ((((uintptr_t)d_a) | ((uintptr_t)d_b)) & 15) return fail(x, SNAPHASH_EINVAL, "bases must be 16-byte aligned");
     if (x->open_batch) return fail(x, SNAPHASH_EINVAL, "a streaming batch is open on this ctx");
@@ -1732,11 +1762,13 @@ int snaphash_ranges_equal_device(snaphash_ctx* x, const void* d_a, const uint64_
     }
     c->stats.streams = n;
     return lift(x, c, launch_compare_ranges(c, va, vb, vl, (uint8_t*)d_equal));
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_dir_updated(snaphash_ctx* c, const char* dir_a, const char* dir_b, const char* pfx, char** names_out,
                          size_t* count)
-{
+try {
     if (!c || !dir_a || !dir_b || !names_out || !count) return fail(c, SNAPHASH_EINVAL, "bad argument");
     *names_out = nullptr;
     *count = 0;
@@ -1771,6 +1803,8 @@ int snaphash_dir_updated(snaphash_ctx* c, const char* dir_a, const char* dir_b, 
     *names_out = p;
     *count = k;
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 // ---- host-side pieces ------------------------------------------------------------------
@@ -1778,7 +1812,7 @@ int snaphash_dir_updated(snaphash_ctx* c, const char* dir_a, const char* dir_b, 
 struct snaphash_records { std::vector<Record> v; };
 
 int snaphash_walk(const char* build_dir, snaphash_records** out)
-{
+try {
     if (!build_dir || !out) return SNAPHASH_EINVAL;
     snaphash_records* r = new (std::nothrow) snaphash_records();
     if (!r) return SNAPHASH_ENOMEM;
@@ -1787,10 +1821,12 @@ int snaphash_walk(const char* build_dir, snaphash_records** out)
     if (rc) { delete r; errno = en; return rc; }
     *out = r;
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 size_t snaphash_records_count(const snaphash_records* r) { return r ? r->v.size() : 0; }
 int snaphash_records_get(const snaphash_records* r, size_t i, snaphash_record* out)
-{
+try {
     if (!r || !out || i >= r->v.size()) return SNAPHASH_EINVAL;
     const Record& x = r->v[i];
     out->name = x.name.c_str();
@@ -1799,11 +1835,13 @@ int snaphash_records_get(const snaphash_records* r, size_t i, snaphash_record* o
     out->size = x.size;
     out->path = x.path.c_str();
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 void snaphash_records_free(snaphash_records* r) { delete r; }
 
 int snaphash_parse_yaml(const char* yaml, size_t yaml_len, snaphash_records** out, char archive_hex[129])
-{
+try {
     if (!yaml || !out) return SNAPHASH_EINVAL;
     ParsedHashes ph;
     int rc = parse_yaml(yaml, yaml_len, ph);
@@ -1822,6 +1860,8 @@ int snaphash_parse_yaml(const char* yaml, size_t yaml_len, snaphash_records** ou
     if (archive_hex) snprintf(archive_hex, 129, "%s", ph.archive_hex.c_str());
     *out = r;
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 const char* snaphash_records_sha512_hex(const snaphash_records* r, size_t i)
@@ -1831,7 +1871,7 @@ const char* snaphash_records_sha512_hex(const snaphash_records* r, size_t i)
 
 int snaphash_emit_yaml(const snaphash_records* r, const uint8_t archive_digest[64], const uint8_t* file_digests,
                        char** yaml_out, size_t* yaml_len)
-{
+try {
     if (!r || !archive_digest || !yaml_out) return SNAPHASH_EINVAL;
     if (!file_digests)
         for (const Record& rec : r->v)
@@ -1846,6 +1886,8 @@ int snaphash_emit_yaml(const snaphash_records* r, const uint8_t archive_digest[6
     *yaml_out = p;
     if (yaml_len) *yaml_len = y.size();
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_mode_string(uint32_t st_mode, char out[11]) { return out ? mode_string(st_mode, out) : SNAPHASH_EINVAL; }
@@ -1854,7 +1896,7 @@ int snaphash_lpt_assign(const uint64_t* lens, size_t n, int nshards, int32_t* sh
 
 int snaphash_fill_synthetic_device(snaphash_ctx* x, void* d_base, const uint64_t* offsets, const uint64_t* lens,
                                    const uint64_t* file_index, size_t n)
-{
+try {
     if (!x || (n && (!d_base || !offsets || !lens || !file_index))) return fail(x, SNAPHASH_EINVAL, "bad argument");
     if (n == 0) return SNAPHASH_OK;
     DevCtx* c = x->d0();
@@ -1874,6 +1916,8 @@ int snaphash_fill_synthetic_device(snaphash_ctx* x, void* d_base, const uint64_t
     (void)hipFree(d);
     if (e != hipSuccess) return fail(x, SNAPHASH_EDEVICE, std::string("fill_synthetic: ") + hipGetErrorString(e));
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 // ---- diagnostics ------------------------------------------------------------------------
@@ -1902,20 +1946,24 @@ void snaphash_get_stats(const snaphash_ctx* c, snaphash_stats* out)
 }
 
 int snaphash_get_stats_ex(const snaphash_ctx* c, snaphash_stats_ex* out)
-{
+try {
     if (!c || !out || out->struct_size < sizeof(snaphash_stats_ex)) return SNAPHASH_EINVAL;
     *out = c->ex;
     out->struct_size = sizeof(snaphash_stats_ex);
     out->n_devices = (uint32_t)c->dev.size();
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 int snaphash_get_device_stats(const snaphash_ctx* c, uint32_t i, int32_t* device, snaphash_stats* out)
-{
+try {
     if (!c || i >= c->dev.size()) return SNAPHASH_EINVAL;
     if (device) *device = c->dev[i]->device;
     if (out) *out = c->dev[i]->stats;
     return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
 }
 
 } // extern "C"

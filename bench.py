@@ -220,6 +220,8 @@ def e2e_build(ctx, total_mib=1024):
     from oracle import oracle
     from snappy_amd import synthetic
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    if base and shutil.disk_usage(base).free < (total_mib << 20) * 2 + (1 << 30):
+        total_mib = max(64, int((shutil.disk_usage(base).free - (1 << 30)) // (2 << 20)))  # the tree and its archive must fit
     tmp = tempfile.mkdtemp(prefix="snaphash_build_", dir=base)
     try:
         build = os.path.join(tmp, "build")
@@ -396,11 +398,26 @@ def main():
             del job["data"]
             torch.cuda.empty_cache()
             ectx = Context(device=local_rank, kernel=kern)  # own stream and staging engine
-            end_to_end = {"buffers": e2e_buffers(ectx, host, job["my_off"], job["my_lens"], digests)}
+            end_to_end = {}
+
+            def leg(name, fn):
+                # an auxiliary leg that cannot run here (no room in /dev/shm, ...) is recorded, it never costs the headline
+                # line; a PARITY FAILURE is a SystemExit and still ends the run
+                try:
+                    return fn()
+                except Exception as e:  # noqa: BLE001
+                    end_to_end[name] = {"error": repr(e)[:300]}
+                    return None
+            r = leg("buffers", lambda: e2e_buffers(ectx, host, job["my_off"], job["my_lens"], digests))
+            if r is not None:
+                end_to_end["buffers"] = r
             if mode == "full":
-                end_to_end["tree"], cpu = e2e_tree(ectx, host, job["my_off"], job["my_lens"], args.e2e_files,
-                                                   args.cpu_seconds)
-                end_to_end["build"] = e2e_build(ectx)
+                r = leg("tree", lambda: e2e_tree(ectx, host, job["my_off"], job["my_lens"], args.e2e_files, args.cpu_seconds))
+                if r is not None:
+                    end_to_end["tree"], cpu = r
+                r = leg("build", lambda: e2e_build(ectx))
+                if r is not None:
+                    end_to_end["build"] = r
             ectx.close()
             del host
         if args.cpu_seconds > 0:

@@ -45,6 +45,7 @@ namespace {
 
 constexpr uint64_t kDefaultStaging = 256ull << 20;
 constexpr uint64_t kAlign = 256;          // placement of a segment inside a staging buffer
+constexpr uint64_t kMinSegment = 64u << 10; // least a stream is given of a slot, unless it ends there
 constexpr uint32_t kTargetStreams = 4096; // streams per batch the engine aims for (keeps the kernel ahead of PCIe)
 
 struct EventPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; }; // kind 0 SHA-512 kernels, 1 h2d, 2 deflate kernels
@@ -429,18 +430,28 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     active.reserve(n);
     for (size_t i = 0; i < n; ++i)
         if (src[i].gpu_len > 0 || src[i].len == 0) active.push_back((uint32_t)i); // a prefix of 0 bytes needs no launch
+    // longest first: the streams that set the makespan are served in every batch from the first one on
+    std::stable_sort(active.begin(), active.end(), [&](uint32_t a, uint32_t b) { return src[a].gpu_len > src[b].gpu_len; });
     std::atomic<int> first_err{0};
     std::atomic<int64_t> first_err_src{-1};
     std::vector<ReadOp> ops;
     const uint64_t S = c->staging;
     unsigned batch = 0;
+    double t_wait = 0, t_plan = 0, t_read = 0, t_launch = 0; // where the host side of the engine spends its time (SNAPHASH_TRACE_TREE)
 
     while (!active.empty()) {
         Slot& sl = c->slot[batch & 1];
+        const double tb0 = now_ms();
         if (sl.busy) { HIP_TRY(c, hipEventSynchronize(sl.done)); sl.busy = false; }
-        const uint64_t target = std::min<uint64_t>(active.size(), kTargetStreams);
-        uint64_t quota = (S / target) & ~(uint64_t)(kAlign - 1);
-        if (quota < kAlign) quota = kAlign;
+        const double tb1 = now_ms();
+        t_wait += tb1 - tb0;
+        // What a stream gets of this slot: its share by remaining length (so that long and short streams end in the
+        // same batch -- a long stream served a fixed slice per batch would still be running, alone, long after the
+        // others: the per-stream rate of the kernels is what it is), but at least kMinSegment (a file is opened once per
+        // batch it appears in).  Equal streams (config 2) fill a slot kTargetStreams at a time, as before.
+        long double total_rem = 0;
+        for (uint32_t id : active) total_rem += (long double)(src[id].gpu_len - done[id]);
+        const uint64_t floor_q = std::max<uint64_t>(kMinSegment, (S / kTargetStreams) & ~(uint64_t)(kAlign - 1));
         rc = ensure_jobs(c, &sl.h_jobs, &sl.d_jobs, &sl.jobs_cap, active.size());
         if (rc) return rc;
 
@@ -453,7 +464,9 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         for (uint32_t id : active) {
             if (full) { still.push_back(id); continue; }
             const uint64_t rem = src[id].gpu_len - done[id];
-            const uint64_t take = rem <= quota ? rem : quota; // quota is a multiple of 128
+            uint64_t quota = total_rem > (long double)S ? (uint64_t)((long double)rem * (long double)S / total_rem) : rem;
+            quota = std::max(quota & ~(uint64_t)(kAlign - 1), floor_q); // a multiple of 128: segments are whole blocks
+            const uint64_t take = rem <= quota ? rem : quota;
             const uint64_t at = (used + kAlign - 1) & ~(uint64_t)(kAlign - 1);
             if (at + take > S) { full = true; still.push_back(id); continue; }
             const bool last = take == rem;
@@ -472,9 +485,13 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
             if (!last) still.push_back(id);
         }
         active.swap(still);
+        const double tb2 = now_ms();
+        t_plan += tb2 - tb1;
 
         run_reads(src, ops, first_err, first_err_src);
         if (first_err.load()) break;
+        const double tb3 = now_ms();
+        t_read += tb3 - tb2;
 
         if (used) { // copy stream: the slot's previous kernel was already waited for above
             EventPair* ev = next_events(c, 1);
@@ -488,9 +505,14 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         HIP_TRY(c, hipEventRecord(sl.done, c->stream));
         sl.busy = true;
         ++batch;
+        t_launch += now_ms() - tb3;
     }
 
+    const double ts0 = now_ms();
     rc = sync_ctx(c);
+    if (getenv("SNAPHASH_TRACE_TREE"))
+        fprintf(stderr, "snaphash engine %d: %u batches; waiting for a slot %.1f ms, planning %.1f ms, reads %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
+                c->index, batch, t_wait, t_plan, t_read, t_launch, now_ms() - ts0);
     c->slot[0].busy = c->slot[1].busy = false;
     if (rc) return rc;
     if (first_err.load()) {
@@ -855,25 +877,58 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
 // sizes (may be NULL): the length each path is expected to have (the walk's lstat, build.go:240-252);
 // without it the length comes from stat() here.  Either way a file that is shorter or longer when it
 // is read fails the call (io.Copy reads to EOF: the record's size and digest must describe the same bytes).
+// os.Open follows symlinks (helpers.go:189); a directory opens but its read fails with EISDIR.  The first path
+// (in list order) that cannot be hashed, or -1; what the reference's serial loop would have stopped at.
+static int64_t first_bad_path(const char* const* paths, size_t n, int* err)
+{
+    for (size_t i = 0; i < n; ++i) {
+        struct stat st;
+        int e = 0;
+        if (stat(paths[i], &st) != 0) e = errno;
+        else if (S_ISDIR(st.st_mode)) e = EISDIR;
+        else if (access(paths[i], R_OK) != 0) e = errno;
+        if (e) { *err = e; return (int64_t)i; }
+    }
+    return -1;
+}
+
 int hash_paths(snaphash_ctx* x, const char* const* paths, size_t n, const int64_t* sizes, uint8_t* digests, int32_t* status)
 {
+    // Optimistic: no per-file checks in front (they were two system calls per file, serial: 0.2 s of a 100 000-file
+    // pass); the readers meet any error where it is.  Only the length is needed here: the walk's Lstat supplies it
+    // (build.go:240-252), otherwise one stat.
     std::vector<Source> src(n);
     for (size_t i = 0; i < n; ++i) {
         if (!paths[i]) return fail(x, SNAPHASH_EINVAL, "NULL path");
-        struct stat st;
-        int err = 0;
-        // os.Open follows symlinks (helpers.go:189); a directory opens but its read fails with EISDIR
-        if (stat(paths[i], &st) != 0) err = errno;
-        else if (S_ISDIR(st.st_mode)) err = EISDIR;
-        else if (access(paths[i], R_OK) != 0) err = errno;
-        if (err) {
-            if (status) { for (size_t k = 0; k < n; ++k) status[k] = 0; status[i] = err; }
-            return fail(x, SNAPHASH_EIO, std::string(paths[i]) + ": " + strerror(err));
-        }
         src[i].path = paths[i];
-        src[i].len = (uint64_t)((sizes && sizes[i] >= 0) ? sizes[i] : st.st_size);
+        if (sizes && sizes[i] >= 0) {
+            src[i].len = (uint64_t)sizes[i];
+        } else {
+            struct stat st;
+            int err = 0;
+            if (stat(paths[i], &st) != 0) err = errno;
+            else if (S_ISDIR(st.st_mode)) err = EISDIR;
+            if (err) { // an earlier path may be unreadable: the reference would have stopped there
+                int64_t bad = first_bad_path(paths, i + 1, &err);
+                if (bad < 0) bad = (int64_t)i;
+                if (status) { for (size_t k = 0; k < n; ++k) status[k] = 0; status[bad] = err; }
+                return fail(x, SNAPHASH_EIO, std::string(paths[bad]) + ": " + strerror(err));
+            }
+            src[i].len = (uint64_t)st.st_size;
+        }
     }
-    return hash_sources_top(x, src, digests, status);
+    const int rc = hash_sources_top(x, src, digests, status);
+    if (rc == SNAPHASH_EIO) {
+        // Which file a parallel pass trips over first is a matter of timing; the reference's serial loop stops at the
+        // first one in order.  Name that one, if an ordered look finds it.
+        int err = 0;
+        const int64_t bad = first_bad_path(paths, n, &err);
+        if (bad >= 0) {
+            if (status) { for (size_t k = 0; k < n; ++k) status[k] = 0; status[bad] = err; }
+            return fail(x, SNAPHASH_EIO, std::string(paths[bad]) + ": " + strerror(err));
+        }
+    }
+    return rc;
 }
 
 void end_top(snaphash_ctx* x, double t0) { x->stats.wall_ms = now_ms() - t0; }
@@ -1131,7 +1186,9 @@ static int tree_impl(snaphash_ctx* x, const char* build_dir, const char* data_ta
     if (data_tar && stat(data_tar, &st) != 0) return fail(x, SNAPHASH_EIO, std::string(data_tar) + ": " + strerror(errno));
     std::vector<Record> recs;
     int en = 0;
+    const double tw0 = now_ms();
     int rc = walk_tree(build_dir, recs, &en);
+    const double tw1 = now_ms();
     if (rc) return fail(x, rc, rc == SNAPHASH_EIO ? std::string(build_dir) + ": " + strerror(en) : "Unknown file mode");
     for (const Record& r : recs)
         if (!plain_safe_name(r.name)) return fail(x, SNAPHASH_ENAME, "name needs YAML quoting: " + r.name);
@@ -1141,11 +1198,17 @@ static int tree_impl(snaphash_ctx* x, const char* build_dir, const char* data_ta
     for (const Record& r : recs)
         if (r.is_regular) { paths.push_back(r.path.c_str()); sizes.push_back(r.size); } // info.Size() of the walk's Lstat (build.go:240-252)
     std::vector<uint8_t> dig(paths.size() * 64 + 64);
+    const double th0 = now_ms();
     rc = hash_paths(x, paths.data(), paths.size(), sizes.data(), dig.data(), nullptr);
+    const double th1 = now_ms();
     if (rc) return rc;
     const uint8_t* arch = data_tar ? dig.data() : archive_digest;
     const uint8_t* files = data_tar ? dig.data() + 64 : dig.data();
-    return emit_yaml(recs, arch, files, yaml);
+    rc = emit_yaml(recs, arch, files, yaml);
+    if (getenv("SNAPHASH_TRACE_TREE"))
+        fprintf(stderr, "snaphash tree: walk %.1f ms (%zu records), hash %.1f ms (%zu streams), yaml %.1f ms (%zu bytes)\n", tw1 - tw0,
+                recs.size(), th1 - th0, paths.size(), now_ms() - th1, yaml.size());
+    return rc;
 }
 
 static int write_yaml_file(snaphash_ctx* x, const char* build_dir, const std::string& y)

@@ -7,6 +7,7 @@ import os
 import re
 import stat
 
+import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
@@ -71,6 +72,45 @@ def test_walk_matches_reference_rules(built_lib, tmp_path):
     assert stat.S_ISLNK(by["link-to-dir"]["st_mode"])
     # trailing slash on the root is tolerated
     assert [r["name"] for r in _lib.walk(str(b) + "/")] == [r["name"] for r in recs]
+
+
+def test_walk_large_tree_parallel_lstat_keeps_walk_order(built_lib, tmp_path):
+    """The walk lists names serially (by directory-entry type) and Lstats in parallel: on a tree big enough for
+    several Lstat threads (> 4096 entries) the records must still be filepath.Walk's -- a plain recursive
+    sorted-listdir + lstat in Python is the third opinion (names, order, modes, sizes); and a fifo deep inside is
+    still the EMODE the serial loop would raise, wherever the threads are."""
+    from snappy_amd import _lib, SnaphashError
+    rng = np.random.default_rng(4)
+    b = tmp_path / "big"
+    b.mkdir()
+    for d in range(60):
+        dn = b / ("d%02d%s" % (d, "-x" if d % 7 == 0 else ""))  # 'd00-x' sorts before 'd00/...' children would: per-directory order
+        dn.mkdir()
+        for f in range(80):
+            (dn / ("f%03d" % f)).write_bytes(b"x" * int(rng.integers(0, 50)))
+        if d % 9 == 0:
+            (dn / "sub").mkdir()
+            (dn / "sub" / "leaf").write_bytes(b"leaf")
+            os.symlink("sub", str(dn / "sub-link"))
+    (b / "DEBIAN").mkdir()
+    (b / "DEBIAN" / "control").write_bytes(b"c")
+
+    def pywalk(path, rel, out):
+        st = os.lstat(path)
+        if rel and not ("/" + rel).startswith("/DEBIAN"):
+            out.append((rel, st.st_mode, st.st_size if stat.S_ISREG(st.st_mode) else 0))
+        if stat.S_ISDIR(st.st_mode):
+            for name in sorted(os.listdir(path), key=os.fsencode):
+                pywalk(os.path.join(path, name), (rel + "/" + name) if rel else name, out)
+    want = []
+    pywalk(str(b), "", want)
+    assert len(want) > 4096
+    recs = _lib.walk(str(b))
+    assert [(r["name"], r["st_mode"], r["size"]) for r in recs] == want
+    os.mkfifo(str(b / "d33" / "f040-pipe"))
+    with pytest.raises(SnaphashError) as e:
+        _lib.walk(str(b))
+    assert e.value.code == _lib.EMODE
 
 
 def test_walk_fifo_is_unknown_mode(built_lib, tmp_path):

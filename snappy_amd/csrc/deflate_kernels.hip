@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __re
             __builtin_amdgcn_wave_barrier();
         }
         uint32_t mlen = 0, dist = 0;
-        if (canmatch) {
+        if (canmatch && pos >= skip_until) { // a position inside the match that reaches into this tile can start no token
             const uint32_t maxl = (len - pos < 258u) ? len - pos : 258u;
             for (uint32_t k = 0; k < 4u; ++k) { // newest first; the longest wins, ties stay with the nearer one
                 const uint32_t e = (uint32_t)(cand >> (48u - 16u * k)) & 0xffffu;

@@ -8,6 +8,7 @@
 //   snappy/hashes.go:93-110    fileHash / hashesYaml field order and omitempty
 //   snappy/hashes_test.go:89-103  the byte layout yaml.v2 gives that schema
 #include "hostpass.h"
+#include "walk.h"
 
 #include <dirent.h>
 #include <errno.h>
@@ -56,95 +57,14 @@ int mode_parse(const char* s, uint32_t* st_mode)
 
 // ---- filepath.Walk as writeHashes drives it ------------------------------------
 
-// Two phases.  (1) Serial: the names, in Walk's order (per directory: readdir, byte-wise sort, pre-order), descending by
-// the directory entry's type where the filesystem gives one (an Lstat-style type: a symlink to a directory is not
-// descended, exactly as Walk with Lstat) -- one opendir per directory instead of one lstat per entry.  (2) Parallel:
-// the Lstat of every entry.  The first error in Walk order is the one reported, as the serial loop would.
-namespace {
-struct WalkEntry {
-    std::string path;
-    struct stat st;
-    bool have_st = false;
-};
-
-// appends path's children (recursively); `path` itself is already in `ents`.  Returns the index of the entry
-// whose directory could not be read (errno in *err_no), or -1.
-static int64_t walk_names(const std::string& path, std::vector<WalkEntry>& ents, size_t self, int* err_no)
+// The records of the entries writeHashes' callback keeps (walk.h gives the entries in Walk's order with their Lstat).
+// SNAPHASH_EMODE for the first entry whose type yamlFileMode cannot express (hashes.go:33-57).
+int records_from_entries(const std::vector<WalkEntry>& ents, std::vector<Record>& out)
 {
-    DIR* d = opendir(path.c_str());
-    if (!d) { *err_no = errno; return (int64_t)self; }
-    std::vector<std::pair<std::string, unsigned char>> names;
-    while (struct dirent* de = readdir(d)) {
-        if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
-        names.emplace_back(de->d_name, de->d_type);
-    }
-    closedir(d);
-    std::sort(names.begin(), names.end(), [](const auto& a, const auto& b) { return a.first < b.first; }); // sort.Strings: byte-wise
-    for (const auto& nt : names) {
-        WalkEntry e;
-        e.path = path + "/" + nt.first;
-        bool is_dir = nt.second == DT_DIR;
-        if (nt.second == DT_UNKNOWN) { // this filesystem does not say: look now
-            if (lstat(e.path.c_str(), &e.st) != 0) { *err_no = errno; ents.push_back(std::move(e)); return (int64_t)ents.size() - 1; }
-            e.have_st = true;
-            is_dir = S_ISDIR(e.st.st_mode);
-        }
-        const size_t me = ents.size();
-        ents.push_back(std::move(e));
-        if (is_dir) {
-            const std::string sub = ents[me].path; // ents may reallocate below
-            const int64_t bad = walk_names(sub, ents, me, err_no);
-            if (bad >= 0) return bad;
-        }
-    }
-    return -1;
-}
-} // namespace
-
-int walk_tree(const char* build_dir, std::vector<Record>& out, int* err_no)
-{
-    std::string root(build_dir);
-    while (root.size() > 1 && root.back() == '/') root.pop_back();
-    const size_t rootlen = root.size();
-    if (err_no) *err_no = 0;
-    std::vector<WalkEntry> ents(1);
-    ents[0].path = root;
-    if (lstat(root.c_str(), &ents[0].st) != 0) { if (err_no) *err_no = errno; return SNAPHASH_EIO; }
-    ents[0].have_st = true;
-    int dir_errno = 0;
-    int64_t dir_bad = -1; // entry whose children could not be listed (or whose look-ahead Lstat failed)
-    if (S_ISDIR(ents[0].st.st_mode)) dir_bad = walk_names(root, ents, 0, &dir_errno);
-
-    // phase 2: Lstat of every entry, in parallel; per-thread first failure
-    const size_t n = ents.size();
-    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(12u, std::max(1u, std::thread::hardware_concurrency())), n / 2048));
-    std::vector<int64_t> bad(T, -1);
-    std::vector<int> bad_errno(T, 0);
-    auto work = [&](unsigned t) {
-        const size_t lo = n * t / T, hi = n * (t + 1) / T;
-        for (size_t i = lo; i < hi; ++i) {
-            if (ents[i].have_st) continue;
-            if (lstat(ents[i].path.c_str(), &ents[i].st) != 0) { bad[t] = (int64_t)i; bad_errno[t] = errno; return; }
-            ents[i].have_st = true;
-        }
-    };
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
-    int64_t first_bad = -1;
-    int first_errno = 0;
-    for (unsigned t = 0; t < T; ++t)
-        if (bad[t] >= 0 && (first_bad < 0 || bad[t] < first_bad)) { first_bad = bad[t]; first_errno = bad_errno[t]; }
-    // a directory that could not be listed fails AFTER its own Lstat and record, before anything behind it
-    if (dir_bad >= 0 && (first_bad < 0 || dir_bad < first_bad)) { first_bad = dir_bad; first_errno = dir_errno; }
-    const size_t limit = first_bad >= 0 ? (size_t)first_bad + (first_bad == dir_bad && ents[(size_t)first_bad].have_st ? 1 : 0) : n;
-
-    out.reserve(out.size() + limit);
-    for (size_t i = 0; i < limit; ++i) {
-        const WalkEntry& e = ents[i];
+    if (ents.empty()) return SNAPHASH_OK;
+    const size_t rootlen = ents[0].path.size();
+    out.reserve(out.size() + ents.size());
+    for (const WalkEntry& e : ents) {
         const char* rel = e.path.c_str() + rootlen;
         // build.go:229: string prefix, not path component -- "/DEBIAN-extra" is skipped too;
         // build.go:232: the root itself.  The callback returns nil (not SkipDir), so
@@ -158,14 +78,21 @@ int walk_tree(const char* build_dir, std::vector<Record>& out, int* err_no)
         r.is_regular = S_ISREG(e.st.st_mode); // build.go:240
         r.size = r.is_regular ? (int64_t)e.st.st_size : 0;
         char m[11];
-        if (mode_string(e.st.st_mode, m) != SNAPHASH_OK) return SNAPHASH_EMODE; // the first in Walk order (hashes.go:33-57)
+        if (mode_string(e.st.st_mode, m) != SNAPHASH_OK) return SNAPHASH_EMODE;
         out.push_back(std::move(r));
     }
-    if (first_bad >= 0) {
-        if (err_no) *err_no = first_errno;
-        return SNAPHASH_EIO;
-    }
     return SNAPHASH_OK;
+}
+
+int walk_tree(const char* build_dir, std::vector<Record>& out, int* err_no)
+{
+    std::vector<WalkEntry> ents;
+    int e = 0;
+    const int wrc = walk_entries(build_dir, ents, &e, nullptr);
+    if (err_no) *err_no = e;
+    const int rc = records_from_entries(ents, out); // what was visited before a failure may already hold the first error
+    if (rc) return rc;
+    return wrc ? SNAPHASH_EIO : SNAPHASH_OK;
 }
 
 // ---- yaml.v2 emitter for hashesYaml ---------------------------------------------

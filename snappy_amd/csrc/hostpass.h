@@ -34,6 +34,8 @@ struct ParsedHashes {
 int mode_string(uint32_t st_mode, char out[11]);
 int mode_parse(const char* s, uint32_t* st_mode);
 int walk_tree(const char* build_dir, std::vector<Record>& out, int* err_no);
+struct WalkEntry;
+int records_from_entries(const std::vector<WalkEntry>& ents, std::vector<Record>& out);
 bool plain_safe_name(const std::string& s);
 void hex_lower(const uint8_t d[64], char out[128]);
 int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64], const uint8_t* file_digests,

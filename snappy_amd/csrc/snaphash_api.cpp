@@ -38,6 +38,7 @@
 #include "sha512_core.h"
 #include "sha512_kernels.h"
 #include "tarpack.h"
+#include "walk.h"
 
 using namespace snaphash;
 

@@ -1,5 +1,6 @@
 // tarpack.cpp -- see tarpack.h.  Host-only; no hashing, no compression here.
 #include "tarpack.h"
+#include "walk.h"
 
 #include <dirent.h>
 #include <errno.h>
@@ -18,15 +19,17 @@ const uint8_t kGzipHeader[10] = {0x1f, 0x8b, 0x08, 0x00, 0x00, 0x00, 0x00, 0x00,
 
 // ---- filepath.Walk as tarCreate drives it (deb.go:283-341) ------------------------------------
 
-static int plan_rec(const std::string& path, size_t rootlen, const std::string& exclude_prefix, TarPlan& out, int* err_no,
-                    std::string* err_what)
+int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& exclude_prefix, TarPlan& out)
 {
-    struct stat st;
-    if (lstat(path.c_str(), &st) != 0) { *err_no = errno; if (err_what) *err_what = path; return SNAPHASH_EIO; }
-    const bool supported = S_ISREG(st.st_mode) || S_ISLNK(st.st_mode) || S_ISDIR(st.st_mode); // deb.go:290-292
-    const bool excluded = !exclude_prefix.empty() && path.compare(0, exclude_prefix.size(), exclude_prefix) == 0; // deb.go:295-299
-    const bool is_root = path.size() == rootlen; // relativePath == "." (deb.go:309-312)
-    if (supported && !excluded && !is_root) {
+    out.members.clear();
+    const size_t rootlen = ents.empty() ? 0 : ents[0].path.size();
+    for (const WalkEntry& e : ents) {
+        const std::string& path = e.path;
+        const struct stat& st = e.st;
+        const bool supported = S_ISREG(st.st_mode) || S_ISLNK(st.st_mode) || S_ISDIR(st.st_mode); // deb.go:290-292
+        const bool excluded = !exclude_prefix.empty() && path.compare(0, exclude_prefix.size(), exclude_prefix) == 0; // deb.go:295-299
+        const bool is_root = path.size() == rootlen; // relativePath == "." (deb.go:309-312)
+        if (!supported || excluded || is_root) continue;
         TarMember m;
         m.path = path;
         m.name = "." + path.substr(rootlen); // deb.go:309
@@ -42,32 +45,6 @@ static int plan_rec(const std::string& path, size_t rootlen, const std::string& 
         }
         out.members.push_back(std::move(m));
     }
-    if (!S_ISDIR(st.st_mode)) return SNAPHASH_OK;
-    DIR* d = opendir(path.c_str());
-    if (!d) { *err_no = errno; if (err_what) *err_what = path; return SNAPHASH_EIO; }
-    std::vector<std::string> names;
-    while (struct dirent* de = readdir(d)) {
-        if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
-        names.emplace_back(de->d_name);
-    }
-    closedir(d);
-    std::sort(names.begin(), names.end()); // sort.Strings: byte-wise
-    for (const std::string& n : names) {
-        int rc = plan_rec(path + "/" + n, rootlen, exclude_prefix, out, err_no, err_what);
-        if (rc) return rc;
-    }
-    return SNAPHASH_OK;
-}
-
-int tar_plan(const char* source_dir, const std::string& exclude_prefix, TarPlan& out, int* err_no, std::string* err_what)
-{
-    std::string root(source_dir);
-    while (root.size() > 1 && root.back() == '/') root.pop_back();
-    out.members.clear();
-    int e = 0;
-    int rc = plan_rec(root, root.size(), exclude_prefix, out, &e, err_what);
-    if (err_no) *err_no = e;
-    if (rc) return rc;
     uint64_t off = 0;
     for (TarMember& m : out.members) {
         m.hdr_off = off;
@@ -76,6 +53,16 @@ int tar_plan(const char* source_dir, const std::string& exclude_prefix, TarPlan&
     }
     out.total = off + 1024; // tar.Writer.Close: two zero blocks
     return SNAPHASH_OK;
+}
+
+int tar_plan(const char* source_dir, const std::string& exclude_prefix, TarPlan& out, int* err_no, std::string* err_what)
+{
+    std::vector<WalkEntry> ents;
+    int e = 0;
+    const int wrc = walk_entries(source_dir, ents, &e, err_what);
+    if (err_no) *err_no = e;
+    if (wrc) { out.members.clear(); return SNAPHASH_EIO; } // deb.go:286-289: the first Lstat error ends the walk
+    return tar_plan_entries(ents, exclude_prefix, out);
 }
 
 // ---- ustar header ---------------------------------------------------------------------------

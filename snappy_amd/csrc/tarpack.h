@@ -34,6 +34,9 @@ struct TarPlan {
 // prefix to skip (Build passes filepath.Join(sourceDir, "DEBIAN"), deb.go:361-363); empty = none.
 // Returns 0 or a SNAPHASH_E* code; *err_no carries errno for EIO.
 int tar_plan(const char* source_dir, const std::string& exclude_prefix, TarPlan& out, int* err_no, std::string* err_what);
+// the same from a walk already made (walk.h): the fused pass walks once for the archive and for hashes.yaml
+struct WalkEntry;
+int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& exclude_prefix, TarPlan& out);
 
 // The 512-byte ustar header of a member (POSIX.1-1988 ustar as Go's archive/tar writes it: octal
 // fields of width-1 digits + NUL, checksum as six digits + NUL + space, magic "ustar\0" "00").

@@ -13,6 +13,7 @@
 
 #include "../snappy_amd/csrc/deflate_core.h"
 #include "../snappy_amd/csrc/tarpack.cpp"
+#include "../snappy_amd/csrc/walk.cpp"
 
 using namespace snaphash;
 

@@ -252,7 +252,8 @@ def test_hostpass_under_asan_and_ubsan(tmp_path):
     exe = str(tmp_path / "asan_hostpass")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-o", exe, os.path.join(ROOT, "tests", "asan_hostpass.cpp"),
-                           os.path.join(ROOT, "snappy_amd", "csrc", "hostpass.cpp")])
+                           os.path.join(ROOT, "snappy_amd", "csrc", "hostpass.cpp"),
+                           os.path.join(ROOT, "snappy_amd", "csrc", "walk.cpp"), "-pthread"])
     build, tar = trees.make_synthetic_tree(str(tmp_path / "t"), [5, 0, 300, 70000, 12, 1, 2, 3])
     r = subprocess.run([exe, build, os.path.join(GOLDEN, "hashes_simple.yaml")], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300)

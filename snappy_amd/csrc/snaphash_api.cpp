@@ -902,20 +902,32 @@ int hash_paths(snaphash_ctx* x, const char* const* paths, size_t n, const int64_
     for (size_t i = 0; i < n; ++i) {
         if (!paths[i]) return fail(x, SNAPHASH_EINVAL, "NULL path");
         src[i].path = paths[i];
-        if (sizes && sizes[i] >= 0) {
-            src[i].len = (uint64_t)sizes[i];
-        } else {
-            struct stat st;
-            int err = 0;
-            if (stat(paths[i], &st) != 0) err = errno;
-            else if (S_ISDIR(st.st_mode)) err = EISDIR;
-            if (err) { // an earlier path may be unreadable: the reference would have stopped there
-                int64_t bad = first_bad_path(paths, i + 1, &err);
-                if (bad < 0) bad = (int64_t)i;
-                if (status) { for (size_t k = 0; k < n; ++k) status[k] = 0; status[bad] = err; }
-                return fail(x, SNAPHASH_EIO, std::string(paths[bad]) + ": " + strerror(err));
+        if (sizes && sizes[i] >= 0) src[i].len = (uint64_t)sizes[i];
+    }
+    { // the lengths nobody supplied: one stat each, on a few threads when there are many
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(12u, std::max(1u, std::thread::hardware_concurrency())), n / 2048));
+        std::vector<int64_t> bad(T, -1);
+        auto work = [&](unsigned t) {
+            const size_t lo = n * t / T, hi = n * (t + 1) / T;
+            for (size_t i = lo; i < hi; ++i) {
+                if (sizes && sizes[i] >= 0) continue;
+                struct stat st;
+                if (stat(paths[i], &st) != 0 || S_ISDIR(st.st_mode)) { bad[t] = (int64_t)i; return; }
+                src[i].len = (uint64_t)st.st_size;
             }
-            src[i].len = (uint64_t)st.st_size;
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& w : th) w.join();
+        int64_t first = -1;
+        for (unsigned t = 0; t < T; ++t) if (bad[t] >= 0 && (first < 0 || bad[t] < first)) first = bad[t];
+        if (first >= 0) { // an earlier path may be unreadable: the reference would have stopped there
+            int err = EIO;
+            int64_t b = first_bad_path(paths, (size_t)first + 1, &err);
+            if (b < 0) b = first;
+            if (status) { for (size_t k = 0; k < n; ++k) status[k] = 0; status[b] = err; }
+            return fail(x, SNAPHASH_EIO, std::string(paths[b]) + ": " + strerror(err));
         }
     }
     const int rc = hash_sources_top(x, src, digests, status);

@@ -19,6 +19,25 @@ const uint8_t kGzipHeader[10] = {0x1f, 0x8b, 0x08, 0x00, 0x00, 0x00, 0x00, 0x00,
 
 // ---- filepath.Walk as tarCreate drives it (deb.go:283-341) ------------------------------------
 
+// name: up to 100 bytes, or prefix (<= 155) + "/" + name (<= 100) split at a slash
+static bool ustar_name_fits(const std::string& nm, size_t* cut_out)
+{
+    if (cut_out) *cut_out = std::string::npos;
+    if (nm.size() <= 100) return true;
+    for (size_t i = std::min<size_t>(nm.size() - 1, 155); i > 0; --i)
+        if (nm[i] == '/' && nm.size() - i - 1 <= 100 && nm.size() - i - 1 > 0) { if (cut_out) *cut_out = i; return true; }
+    return false;
+}
+
+// "<len> <key>=<value>\n", len counting its own digits
+static std::string pax_record(const char* key, const std::string& value)
+{
+    const size_t body = 1 + strlen(key) + 1 + value.size() + 1; // ' ' key '=' value '\n'
+    size_t len = body + 1;
+    while (std::to_string(len).size() + body != len) len = std::to_string(len).size() + body;
+    return std::to_string(len) + " " + key + "=" + value + "\n";
+}
+
 int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& exclude_prefix, TarPlan& out)
 {
     out.members.clear();
@@ -43,10 +62,16 @@ int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& excl
             const ssize_t n = readlink(path.c_str(), buf, sizeof buf); // os.Readlink, error ignored (deb.go:302)
             if (n > 0) m.linkname.assign(buf, (size_t)n);
         }
+        if (!ustar_name_fits(m.name, nullptr)) m.pax += pax_record("path", m.name);
+        if (m.linkname.size() > 100) m.pax += pax_record("linkpath", m.linkname);
         out.members.push_back(std::move(m));
     }
     uint64_t off = 0;
     for (TarMember& m : out.members) {
+        if (!m.pax.empty()) {
+            m.pax_off = off;
+            off += 512 + (((uint64_t)m.pax.size() + 511) & ~(uint64_t)511);
+        }
         m.hdr_off = off;
         m.data_off = off + 512;
         off += 512 + (((uint64_t)m.size + 511) & ~(uint64_t)511); // content is padded to the 512-byte record
@@ -76,19 +101,19 @@ static void octal(uint8_t* f, int width, uint64_t v) // width-1 digits, zero pad
 int tar_header(const TarMember& m, uint8_t h[512])
 {
     memset(h, 0, 512);
-    // name: up to 100 bytes, or prefix (<= 155) + "/" + name split at a slash
     const std::string& nm = m.name;
+    size_t cut;
     if (nm.size() <= 100) {
         memcpy(h, nm.data(), nm.size());
-    } else {
-        size_t cut = std::string::npos;
-        for (size_t i = std::min<size_t>(nm.size() - 1, 155); i > 0; --i)
-            if (nm[i] == '/' && nm.size() - i - 1 <= 100 && i <= 155) { cut = i; break; }
-        if (cut == std::string::npos || nm.size() - cut - 1 == 0) return SNAPHASH_ENAME;
+    } else if (ustar_name_fits(nm, &cut)) {
         memcpy(h + 345, nm.data(), cut);
         memcpy(h, nm.data() + cut + 1, nm.size() - cut - 1);
+    } else if (m.pax.find(" path=") != std::string::npos) {
+        memcpy(h, nm.data(), 100); // the PAX record in front carries the whole name
+    } else {
+        return SNAPHASH_ENAME;
     }
-    if (m.linkname.size() > 100) return SNAPHASH_ENAME;
+    if (m.linkname.size() > 100 && m.pax.find(" linkpath=") == std::string::npos) return SNAPHASH_ENAME;
     // mode: permission bits + setuid/setgid/sticky + the file type bits, as tar.FileInfoHeader fills it
     uint64_t mode = m.st_mode & 07777;
     if (m.typeflag == '0') mode |= 0100000;
@@ -102,7 +127,7 @@ int tar_header(const TarMember& m, uint8_t h[512])
     octal(h + 136, 12, m.mtime < 0 ? 0 : (uint64_t)m.mtime);
     memset(h + 148, ' ', 8); // checksum field counts as spaces
     h[156] = (uint8_t)m.typeflag;
-    memcpy(h + 157, m.linkname.data(), m.linkname.size());
+    memcpy(h + 157, m.linkname.data(), std::min<size_t>(m.linkname.size(), 100));
     memcpy(h + 257, "ustar", 6); // magic "ustar\0"
     h[263] = '0'; h[264] = '0';  // version "00"
     memcpy(h + 265, "root", 4);  // uname
@@ -114,6 +139,32 @@ int tar_header(const TarMember& m, uint8_t h[512])
     octal(h + 148, 7, sum); // six digits + NUL, then the space that is already there
     h[155] = ' ';
     return SNAPHASH_OK;
+}
+
+void tar_pax_header(const TarMember& m, uint8_t h[512])
+{
+    memset(h, 0, 512);
+    // <dir>/PaxHeaders.0/<file>, cut to the name field
+    const size_t slash = m.name.rfind('/');
+    std::string nm = (slash == std::string::npos ? std::string() : m.name.substr(0, slash + 1)) + "PaxHeaders.0/" +
+                     (slash == std::string::npos ? m.name : m.name.substr(slash + 1));
+    if (nm.size() > 100) nm.resize(100);
+    memcpy(h, nm.data(), nm.size());
+    octal(h + 100, 8, 0);
+    octal(h + 108, 8, 0);
+    octal(h + 116, 8, 0);
+    octal(h + 124, 12, (uint64_t)m.pax.size());
+    octal(h + 136, 12, m.mtime < 0 ? 0 : (uint64_t)m.mtime); // a reader wants a valid ModTime here
+    memset(h + 148, ' ', 8);
+    h[156] = 'x';
+    memcpy(h + 257, "ustar", 6);
+    h[263] = '0'; h[264] = '0';
+    octal(h + 329, 8, 0);
+    octal(h + 337, 8, 0);
+    unsigned sum = 0;
+    for (int i = 0; i < 512; ++i) sum += h[i];
+    octal(h + 148, 7, sum);
+    h[155] = ' ';
 }
 
 // ---- CRC-32 -----------------------------------------------------------------------------------

@@ -23,6 +23,14 @@ struct TarMember {
     char typeflag = '0';  // '0' regular, '2' symlink, '5' directory
     uint64_t hdr_off = 0; // offset of the 512-byte header in the tar stream
     uint64_t data_off = 0; // offset of the content (hdr_off + 512)
+    // A name or link target the ustar fields cannot hold travels in a PAX extended header in front of the member
+    // (POSIX.1-2001 typeflag 'x', records "<len> path=<name>\n" / "<len> linkpath=<target>\n"), as Go's archive/tar
+    // falls back to (its writePAXHeader; pseudo-file name <dir>/PaxHeaders.<pid>/<file>, here with pid 0 so that the
+    // archive is a function of the tree).  pax: the records (empty = none); pax_off: offset of the 'x' header record,
+    // its data follows at pax_off + 512, padded to the record size, then hdr_off.
+    std::string pax;
+    uint64_t pax_off = 0;
+    uint64_t first_off() const { return pax.empty() ? hdr_off : pax_off; }
 };
 
 struct TarPlan {
@@ -40,8 +48,10 @@ int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& excl
 
 // The 512-byte ustar header of a member (POSIX.1-1988 ustar as Go's archive/tar writes it: octal
 // fields of width-1 digits + NUL, checksum as six digits + NUL + space, magic "ustar\0" "00").
-// Returns SNAPHASH_ENAME when the name or link target does not fit the ustar fields.
+// A field that does not fit is truncated when m.pax carries it (the reader takes the PAX record), else SNAPHASH_ENAME.
 int tar_header(const TarMember& m, uint8_t out[512]);
+// The header record of m's PAX extended header (typeflag 'x', size = m.pax.size()).
+void tar_pax_header(const TarMember& m, uint8_t out[512]);
 
 // CRC-32 (IEEE 802.3, the gzip trailer's), slice-by-8, and the combination of the CRCs of two
 // adjacent ranges (the second of len2 bytes).

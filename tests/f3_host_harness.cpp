@@ -209,6 +209,10 @@ int f3_tar_stream(const char* dir, const char* exclude_prefix, uint8_t** out, si
     if (rc) return rc;
     uint8_t* buf = (uint8_t*)calloc(plan.total ? plan.total : 1, 1);
     for (const TarMember& m : plan.members) {
+        if (!m.pax.empty()) {
+            tar_pax_header(m, buf + m.pax_off);
+            memcpy(buf + m.pax_off + 512, m.pax.data(), m.pax.size());
+        }
         rc = tar_header(m, buf + m.hdr_off);
         if (rc) { free(buf); return rc; }
         if (m.typeflag == '0' && m.size) {

@@ -154,12 +154,38 @@ def test_tar_stream_matches_tarcreate_rules(f3, tmp_path):
     assert [x.rstrip("/") for x in lst if x] == names
 
 
-def test_tar_name_too_long_is_refused(f3, tmp_path):
+def test_tar_long_names_travel_in_pax_headers(f3, tmp_path):
+    """A name or link target the ustar fields cannot hold (no slash to split at, more than 255 bytes, a target over
+    100) goes out behind a PAX extended header, as Go's archive/tar falls back to (parity of its exact bytes is
+    unpinned: no Go here; the check is that tarfile and coreutils tar read names, targets and contents back)."""
     root = str(tmp_path / "s")
     os.makedirs(root)
-    open(os.path.join(root, "x" * 101), "w").close()  # no slash to split at: does not fit ustar
+    long_file = "x" * 101                                  # no slash to split at
+    deep = os.path.join("d" * 90, "e" * 90, "f" * 90)      # 272 bytes: no prefix/name split fits
+    os.makedirs(os.path.join(root, deep))
+    split_ok = os.path.join("p" * 80, "q" * 80)            # 161 bytes: the ustar prefix split still holds it
+    os.makedirs(os.path.join(root, split_ok))
+    contents = {long_file: b"long name", os.path.join(deep, "leaf"): b"deep " * 300, os.path.join(split_ok, "y"): b"split"}
+    for rel, data in contents.items():
+        with open(os.path.join(root, rel), "wb") as f:
+            f.write(data)
+    os.symlink("t" * 150, os.path.join(root, "long-link"))
     out, n = ctypes.c_void_p(), ctypes.c_size_t()
-    assert f3.f3_tar_stream(root.encode(), None, ctypes.byref(out), ctypes.byref(n)) == -6  # SNAPHASH_ENAME
+    assert f3.f3_tar_stream(root.encode(), None, ctypes.byref(out), ctypes.byref(n)) == 0
+    stream = ctypes.string_at(out.value, n.value)
+    f3.f3_free(out)
+    tf = tarfile.open(fileobj=io.BytesIO(stream), mode="r:")
+    by = {m.name: m for m in tf.getmembers()}
+    for rel, data in contents.items():
+        assert tf.extractfile(by["./" + rel]).read() == data, rel
+    assert by["./long-link"].issym() and by["./long-link"].linkname == "t" * 150
+    assert "./" + deep in by and by["./" + deep].isdir()
+    assert stream.count(b" path=./") >= 3 and stream.count(b" linkpath=") == 1  # the long file, the deep directory and its leaf; the link
+    assert b"PaxHeaders.0/" + long_file.encode()[:80] in stream
+    raw = stream[by["./" + os.path.join(split_ok, "y")].offset:][:512]
+    assert raw[156:157] == b"0" and raw[345:345 + 3] == b"./p"  # plain ustar prefix split, no PAX in front of it
+    lst = subprocess.run(["tar", "-tvf", "-"], input=stream, stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert long_file in lst and ("t" * 150) in lst and ("f" * 90 + "/leaf") in lst
 
 
 def test_f3_host_code_under_asan_and_ubsan(tmp_path):

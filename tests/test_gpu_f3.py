@@ -132,13 +132,18 @@ def test_tar_create_error_paths_leave_no_archive_and_a_usable_ctx(built_lib, ora
         with pytest.raises(_lib.SnaphashError) as ei:
             c.tar_create(str(tmp_path / "no-such-dir" / "x.tar.gz"), build)
         assert ei.value.code == _lib.EIO
-        # 3. a member name that fits neither the name field nor the prefix split
+        # 3. names the ustar fields cannot hold travel in PAX extended headers (also across slot boundaries: 1 MiB staging)
         long_dir = os.path.join(build, "n" * 120)
         os.makedirs(long_dir)
-        open(os.path.join(long_dir, "m" * 120), "wb").write(b"x")
-        with pytest.raises(_lib.SnaphashError) as ei:
-            c.tar_create(out, build, build + "/DEBIAN")
-        assert ei.value.code == _lib.ENAME and not os.path.exists(out)
+        open(os.path.join(long_dir, "m" * 120), "wb").write(b"x" * 70000)
+        os.symlink("t" * 180, os.path.join(long_dir, "lnk"))
+        yl, _ = c.tar_create(out, build, build + "/DEBIAN", with_hashes=True)
+        assert yl == oracle.hashes_yaml(build, out)
+        tfl = tarfile.open(out, "r:gz")
+        ml = tfl.getmember("./" + "n" * 120 + "/" + "m" * 120)
+        assert tfl.extractfile(ml).read() == b"x" * 70000 and tfl.getmember("./" + "n" * 120 + "/lnk").linkname == "t" * 180
+        tfl.close()
+        os.unlink(out)
         import shutil
         shutil.rmtree(long_dir)
         # ... and the ctx is as good as new
@@ -184,6 +189,12 @@ def test_tar_create_slot_boundaries_random_trees(built_lib, oracle, tmp_path):
                     f.write(data)
             if it % 3 == 0:
                 os.symlink("f00", os.path.join(build, "link"))
+            if it % 2 == 1:  # PAX extended headers (names the ustar fields cannot hold) get to straddle slots too
+                ld = os.path.join(build, "d1", "L" * int(rng.integers(101, 200)))
+                os.makedirs(ld, exist_ok=True)
+                with open(os.path.join(ld, "n" * int(rng.integers(101, 250))), "wb") as f:
+                    f.write(rng.integers(0, 256, size=int(rng.integers(0, 70000)), dtype=np.uint8).tobytes())
+                os.symlink("T" * int(rng.integers(101, 400)), os.path.join(ld, "lnk"))
             p, n = ctypes.c_void_p(), ctypes.c_size_t()
             assert L.f3_tar_stream(build.encode(), (build + "/DEBIAN").encode(), ctypes.byref(p), ctypes.byref(n)) == 0
             want_tar = ctypes.string_at(p.value, n.value)

@@ -224,5 +224,7 @@ int main(int argc, char** argv) {
     deep = os.path.join(root, *(["d" * 30] * 4))  # a 124-byte directory path: members below it need the ustar prefix split
     os.makedirs(deep)
     open(os.path.join(deep, "f" * 60), "w").write("prefix split")
+    open(os.path.join(deep, "g" * 200), "w").write("PAX path record")          # beyond any ustar split
+    os.symlink("t" * 300, os.path.join(deep, "pax-link"))                      # PAX linkpath record
     r = subprocess.run([exe, root, root + "/DEBIAN"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0 and b"asan f3 ok" in r.stdout, r.stderr.decode()[-2000:]

@@ -225,7 +225,7 @@ typedef struct snaphash_targz_stats { /* of the most recent snaphash_tar_create 
  * symlinks and directories only), skips every path that starts with exclude_prefix (NULL = none; Build
  * passes <source_dir>/DEBIAN, deb.go:361-363), names members "./<relative path>", owner root/root (ustar
  * headers; a name or link target they cannot hold travels in a PAX extended header, as archive/tar falls
- * back to; a member of 8 GiB or more is refused), and writes the tar stream through a gzip member into tarname (must end in ".gz": the reference's ".xz"
+ * back to; the size of a member of 8 GiB or more in the base-256 form), and writes the tar stream through a gzip member into tarname (must end in ".gz": the reference's ".xz"
  * branch is an external tool).  The DEFLATE stream is produced on the GPU, block-parallel: it is
  * format-compatible with, not byte-identical to, compress/gzip level 9 (archive-sha512 is defined over
  * whatever bytes are produced, build.go:222).

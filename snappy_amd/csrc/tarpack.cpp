@@ -122,8 +122,14 @@ int tar_header(const TarMember& m, uint8_t h[512])
     octal(h + 100, 8, mode);
     octal(h + 108, 8, 0); // uid: all files belong to root (deb.go:316-319)
     octal(h + 116, 8, 0); // gid
-    if ((uint64_t)m.size >= (1ull << 33)) return SNAPHASH_EINVAL; // 11 octal digits
-    octal(h + 124, 12, m.typeflag == '0' ? (uint64_t)m.size : 0);
+    if ((uint64_t)m.size >= (1ull << 33)) {
+        // 11 octal digits hold 8 GiB - 1: beyond that the binary form every reader of the last decades knows (GNU
+        // base-256: a set top bit, then the value big-endian), as archive/tar writes it for such a member
+        h[124] = 0x80;
+        for (int i = 0; i < 8; ++i) h[124 + 4 + i] = (uint8_t)((uint64_t)m.size >> (56 - 8 * i));
+    } else {
+        octal(h + 124, 12, m.typeflag == '0' ? (uint64_t)m.size : 0);
+    }
     octal(h + 136, 12, m.mtime < 0 ? 0 : (uint64_t)m.mtime);
     memset(h + 148, ' ', 8); // checksum field counts as spaces
     h[156] = (uint8_t)m.typeflag;

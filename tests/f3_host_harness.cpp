@@ -225,5 +225,15 @@ int f3_tar_stream(const char* dir, const char* exclude_prefix, uint8_t** out, si
     *out_len = plan.total;
     return 0;
 }
+// the header record of a regular member of the given size (tests: the fields beyond what a real tree can afford)
+int f3_tar_header_of(const char* name, int64_t size, uint8_t* out512)
+{
+    TarMember m;
+    m.name = name;
+    m.size = size;
+    m.st_mode = 0100644;
+    m.mtime = 1;
+    return tar_header(m, out512);
+}
 void f3_free(void* p) { free(p); }
 }

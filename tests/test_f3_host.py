@@ -188,6 +188,16 @@ def test_tar_long_names_travel_in_pax_headers(f3, tmp_path):
     assert long_file in lst and ("t" * 150) in lst and ("f" * 90 + "/leaf") in lst
 
 
+def test_tar_size_field_beyond_8_gib(f3):
+    """The ustar size field holds 8 GiB - 1 in octal; a larger member gets the base-256 form (a real 8 GiB member
+    would cost minutes of single-stream hashing in a test: the header alone is checked, through tarfile's parser)."""
+    buf = ctypes.create_string_buffer(512)
+    for size in (0, 1, (1 << 33) - 1, 1 << 33, (1 << 40) + 12345):
+        assert f3.f3_tar_header_of(b"./big", ctypes.c_int64(size), buf) == 0
+        ti = tarfile.TarInfo.frombuf(buf.raw, "utf-8", "surrogateescape")
+        assert ti.size == size and ti.name == "./big" and ti.isreg(), size
+
+
 def test_f3_host_code_under_asan_and_ubsan(tmp_path):
     """tarpack.cpp (walk, ustar headers, CRC-32), hostsha.cpp and the serial model of the DEFLATE kernel under
     AddressSanitizer + UBSan (CPU build; GPU sanitizers are not available on the pool): a tree with every member

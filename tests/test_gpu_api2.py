@@ -284,3 +284,28 @@ def test_distinct_contexts_on_concurrent_threads(built_lib, oracle, tmp_path):
         t.join(timeout=300)
     assert not errors, errors
     assert not any(t.is_alive() for t in th)
+
+
+def test_contexts_release_their_device_memory(built_lib, tmp_path):
+    """Every allocation a ctx makes lazily (staging slots, deflate scratch incl. the 1 GiB token scratch of the default
+    staging size, gather buffers, pinned buffers) goes back on snaphash_destroy: ten create / use / destroy cycles
+    leave the device's free memory where it was."""
+    import torch
+    from snappy_amd import Context
+    build, tar = trees.make_synthetic_tree(str(tmp_path), [1000, 70000, 3, 0, 5])
+    os.makedirs(os.path.join(build, "DEBIAN"), exist_ok=True)
+    out = str(tmp_path / "o.tar.gz")
+    torch.cuda.synchronize()
+
+    def cycle():
+        with Context(devices=[0, 0], flags=0) as c:  # two engines: both allocate
+            c.tree(build, tar)
+        with Context() as c:                          # default staging: the large deflate scratch
+            c.tar_create(out, build, build + "/DEBIAN", with_hashes=True)
+            c.gzip_buffer(b"abc" * 100000)
+    cycle()  # warm: the runtime's own pools settle
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(10):
+        cycle()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), (free0, free1)  # a leak of any per-ctx buffer would be hundreds of MiB per cycle

@@ -236,6 +236,15 @@ typedef struct snaphash_targz_stats { /* of the most recent snaphash_tar_create 
 int snaphash_tar_create(snaphash_ctx *ctx, const char *tarname, const char *source_dir, const char *exclude_prefix,
                         char **yaml_out, size_t *yaml_len, uint8_t *archive_digest);
 
+/* The same with tarCreate's own third argument (clickdeb/deb.go:261: `fn tarExcludeFunc`, asked at deb.go:295-299):
+ * keep(path, user) is called on the calling thread with the full path of every regular file, symlink and
+ * directory of the walk, in walk order; zero leaves the entry out (a directory that is left out is still descended,
+ * as in the reference, where fn returning false only skips that one entry).  NULL keeps everything.  From Go: an
+ * //export'ed function as the callback, the closure's state behind `user`. */
+typedef int (*snaphash_keep_fn)(const char *path, void *user);
+int snaphash_tar_create_fn(snaphash_ctx *ctx, const char *tarname, const char *source_dir, snaphash_keep_fn keep, void *user,
+                           char **yaml_out, size_t *yaml_len, uint8_t *archive_digest);
+
 /* The compressor alone: one gzip member (RFC 1952) of a host buffer; *gz_out is malloc'd (snaphash_free). */
 int snaphash_gzip_buffer(snaphash_ctx *ctx, const void *data, size_t n, void **gz_out, size_t *gz_len);
 void snaphash_get_targz_stats(const snaphash_ctx *ctx, snaphash_targz_stats *out);

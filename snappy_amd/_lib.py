@@ -28,7 +28,7 @@ EXPORTS = [
     "snaphash_fill_synthetic_device", "snaphash_strerror", "snaphash_last_error", "snaphash_get_stats",
     "snaphash_get_stats_ex", "snaphash_get_device_stats", "snaphash_tree_ex",
     "snaphash_batch_begin", "snaphash_batch_append", "snaphash_batch_end", "snaphash_batch_finish", "snaphash_batch_abort",
-    "snaphash_tar_create", "snaphash_gzip_buffer", "snaphash_get_targz_stats",
+    "snaphash_tar_create", "snaphash_tar_create_fn", "snaphash_gzip_buffer", "snaphash_get_targz_stats",
 ]
 FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER = 1, 2, 4
 
@@ -273,6 +273,24 @@ class Context:
         self._check(lib().snaphash_tar_create(self._h, os.fsencode(tarname), os.fsencode(source_dir),
                                               os.fsencode(exclude_prefix) if exclude_prefix else None,
                                               ctypes.byref(p) if with_hashes else None, ctypes.byref(n), dig))
+        try:
+            return (ctypes.string_at(p.value, n.value) if with_hashes else None), dig.raw
+        finally:
+            if with_hashes:
+                lib().snaphash_free(p)
+
+    def tar_create_fn(self, tarname, source_dir, keep=None, with_hashes=False):
+        """tarCreate with the reference's own exclude function: keep(path) -> bool (clickdeb/deb.go:261, 295-299)."""
+        KEEP = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)
+        cb = KEEP((lambda path, _u: 1 if keep(os.fsdecode(path)) else 0) if keep else 0)
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        dig = ctypes.create_string_buffer(64)
+        f = lib().snaphash_tar_create_fn
+        f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, KEEP, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                      ctypes.c_char_p]
+        self._check(f(self._h, os.fsencode(tarname), os.fsencode(source_dir), cb, None,
+                      ctypes.cast(ctypes.byref(p), ctypes.c_void_p) if with_hashes else None,
+                      ctypes.cast(ctypes.byref(n), ctypes.c_void_p), dig))
         try:
             return (ctypes.string_at(p.value, n.value) if with_hashes else None), dig.raw
         finally:

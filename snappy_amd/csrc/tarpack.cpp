@@ -38,7 +38,7 @@ static std::string pax_record(const char* key, const std::string& value)
     return std::to_string(len) + " " + key + "=" + value + "\n";
 }
 
-int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& exclude_prefix, TarPlan& out)
+int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& exclude_prefix, TarPlan& out, TarKeepFn keep, void* user)
 {
     out.members.clear();
     const size_t rootlen = ents.empty() ? 0 : ents[0].path.size();
@@ -48,7 +48,9 @@ int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& excl
         const bool supported = S_ISREG(st.st_mode) || S_ISLNK(st.st_mode) || S_ISDIR(st.st_mode); // deb.go:290-292
         const bool excluded = !exclude_prefix.empty() && path.compare(0, exclude_prefix.size(), exclude_prefix) == 0; // deb.go:295-299
         const bool is_root = path.size() == rootlen; // relativePath == "." (deb.go:309-312)
-        if (!supported || excluded || is_root) continue;
+        if (!supported || excluded) continue;
+        if (keep && !keep(path.c_str(), user)) continue; // deb.go:295-299: fn is asked before the root is dropped
+        if (is_root) continue;
         TarMember m;
         m.path = path;
         m.name = "." + path.substr(rootlen); // deb.go:309

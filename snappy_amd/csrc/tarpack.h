@@ -44,7 +44,11 @@ struct TarPlan {
 int tar_plan(const char* source_dir, const std::string& exclude_prefix, TarPlan& out, int* err_no, std::string* err_what);
 // the same from a walk already made (walk.h): the fused pass walks once for the archive and for hashes.yaml
 struct WalkEntry;
-int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& exclude_prefix, TarPlan& out);
+// keep (may be NULL): tarCreate's exclude function (deb.go:261, 295-299), called with the full path of every supported
+// entry in walk order on the calling thread; zero leaves the entry out
+typedef int (*TarKeepFn)(const char* path, void* user);
+int tar_plan_entries(const std::vector<WalkEntry>& ents, const std::string& exclude_prefix, TarPlan& out, TarKeepFn keep = nullptr,
+                     void* user = nullptr);
 
 // The 512-byte ustar header of a member (POSIX.1-1988 ustar as Go's archive/tar writes it: octal
 // fields of width-1 digits + NUL, checksum as six digits + NUL + space, magic "ustar\0" "00").

@@ -244,3 +244,41 @@ def test_tarcreate_as_the_reference_tests_it(built_lib, tmp_path):
     assert asked == [builddir, builddir + "/etc", builddir + "/exclude-me", builddir + "/foo", builddir + "/link-to-foo"]
     with pytest.raises(Exception):
         clickdeb.tarCreate(str(tmp_path / "x.tar.zz"), builddir, None)  # "unknown compression extension"
+
+
+def test_gpu_deflate_equals_model_on_random_structures(built_lib, f3):  # noqa: F811
+    """Forty synthetic inputs made of the things a parse can trip over -- copies from every distance up to beyond the
+    window, of every length up to beyond 258, runs, literal bursts, cut at awkward sizes around the chunk and tile
+    sizes -- through the GPU compressor: gzip inflates each to its input and the bytes equal the CPU model's."""
+    import ctypes
+    from snappy_amd import Context
+    rng = np.random.default_rng(77)
+    with Context(staging_bytes=1 << 18) as c:
+        for it in range(40):
+            target = int(rng.choice([63, 64, 65, 16383, 16384, 16385, 32768 + 5, int(rng.integers(1, 220000))]))
+            buf = bytearray()
+            while len(buf) < target:
+                kind = int(rng.integers(0, 5))
+                if kind == 0 or len(buf) < 8:
+                    buf += rng.integers(0, 256, size=int(rng.integers(1, 300)), dtype=np.uint8).tobytes()
+                elif kind == 1:
+                    buf += bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 1200))
+                elif kind == 2:  # a copy from anywhere behind, any length: overlapping copies included
+                    dist = int(rng.integers(1, min(len(buf), 70000) + 1))
+                    for _ in range(int(rng.integers(3, 700))):
+                        buf.append(buf[-dist])
+                elif kind == 3:  # text-like: few symbols
+                    buf += bytes(rng.choice(np.frombuffer(b"etaoin shrdlu\n", dtype=np.uint8), size=int(rng.integers(1, 2000))))
+                else:            # the same short phrase again and again with one byte changed
+                    phrase = bytearray(rng.integers(97, 123, size=int(rng.integers(4, 40)), dtype=np.uint8).tobytes())
+                    for _ in range(int(rng.integers(1, 60))):
+                        phrase[int(rng.integers(0, len(phrase)))] = int(rng.integers(97, 123))
+                        buf += phrase
+            data = bytes(buf[:target])
+            gz = c.gzip_buffer(data)
+            assert gzip.decompress(gz) == data, it
+            n = ctypes.c_size_t()
+            p = f3.f3_model_gzip2(data, len(data), 1 << 18, ctypes.byref(n))
+            model = ctypes.string_at(p, n.value)
+            f3.f3_free(p)
+            assert gz == model, (it, len(data))

@@ -20,11 +20,15 @@ Prints ONE JSON line on rank 0:
   roofline      the dominant kernel against the 8 TB/s HBM-read roofline
                 (algorithmic bytes = file bytes hashed); kernel time from HIP
                 events on the launch stream (library stats)
-  end_to_end    N = 1 only: host buffers -> digests (snaphash_sha512_buffers) and
-                on-disk tree -> hashes.yaml (snaphash_tree), the latter compared
-                byte for byte with the oracle's hashes.yaml; and `build`: Build's
-                data step fused (tar + GPU DEFLATE + archive digest + hashes.yaml)
-                on a 1 GiB text tree
+  end_to_end    every N: `buffers_sharded` -- each rank hashes ITS LPT shard of the one
+                tree from host memory through snaphash_sha512_buffers (its own PCIe
+                link, staging on the GPU's NUMA node), timed between barriers, MAX over
+                ranks: the one rate of this path that shards.
+                N = 1 also: on-disk tree -> hashes.yaml (snaphash_tree, compared byte
+                for byte with the oracle's), `package` (a tree beside an archive of its
+                own size, the library's DEFAULT configuration) and `build`: Build's data
+                step fused (tar + GPU DEFLATE + archive digest + hashes.yaml) on a 1 GiB
+                text tree
   cpu_baseline  the oracle (C restatement of the reference's serial loop) timed
                 on this box's host cores over a bounded sample of the same tree
 """
@@ -119,33 +123,94 @@ def cpu_baseline_buffers(sizes, budget_s):
 # ------------------------------------------------------------------------------------------
 # end_to_end legs (N = 1): the whole pass as a caller sees it
 # ------------------------------------------------------------------------------------------
-def e2e_buffers(ctx, host, offsets, lens, want_digests):
-    """host memory in, digests out: pinned staging, double-buffered H2D, chunked segments."""
+def e2e_buffers_sharded(ctx, host, offsets, lens, want_digests, total_bytes, world, fence, allmax, gather):
+    """Every rank: ITS shard of the one tree, host memory in, digests out (pinned staging on the GPU's NUMA node,
+    double-buffered H2D over the rank's own PCIe link, kernels).  Timed between barriers, MAX over ranks; the value is
+    the whole tree's bytes over that time.  At N = 1 this is the plain host-buffers leg."""
     import ctypes
     from snappy_amd import _lib
     n = len(lens)
-    ptrs = (ctypes.c_void_p * n)(*[host.ctypes.data + int(o) for o in offsets])
-    clens = (ctypes.c_uint64 * n)(*[int(x) for x in lens])
-    out = ctypes.create_string_buffer(64 * n)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[host.ctypes.data + int(o) for o in offsets])
+    clens = (ctypes.c_uint64 * max(n, 1))(*[int(x) for x in lens])
+    out = ctypes.create_string_buffer(64 * max(n, 1))
     best = None
     for _ in range(3):
+        fence()
         t0 = time.perf_counter()
         rc = _lib.lib().snaphash_sha512_buffers(ctx._h, ptrs, clens, n, out)
-        dt = time.perf_counter() - t0
+        mine = time.perf_counter() - t0
+        fence()
+        dt = allmax(time.perf_counter() - t0)
         if rc:
             raise SystemExit("snaphash_sha512_buffers failed: %d" % rc)
         st = ctx.stats()
         if best is None or dt < best[0]:
-            best = (dt, st)
-    got = np.frombuffer(out.raw, dtype=np.uint8).reshape(n, 64)
+            best = (dt, mine, st)
+    got = np.frombuffer(out.raw, dtype=np.uint8)[:64 * n].reshape(n, 64)
     if not np.array_equal(got, want_digests):
         raise SystemExit("PARITY FAILURE: host-buffer digests differ from the HBM-resident pass")
-    dt, st = best
-    total = int(np.sum(lens))
-    return {"what": "host buffers -> snaphash_sha512_buffers -> digests on the host (pinned staging, H2D, kernels)",
-            "ms": round(dt * 1e3, 2), "GiBps": round(total / 2**30 / dt, 2), "h2d_ms": round(st["h2d_ms"], 2),
-            "kernel_ms": round(st["kernel_ms"], 2), "launches": int(st["launches"]),
-            "parity": "digest vector identical to the HBM-resident pass", "best_of": 3}
+    dt, mine, st = best
+    info = ctx.engine_info(0)
+    per_rank = gather({"ms": round(mine * 1e3, 2), "h2d_ms": round(st["h2d_ms"], 2), "kernel_ms": round(st["kernel_ms"], 2),
+                       "bytes": int(np.sum(lens)), "streams": n, "launches": int(st["launches"]),
+                       "numa_node": info["numa_node"], "staging_node": info["staging_node"], "fill_threads": info["fill_threads"]})
+    out = {"what": "host buffers -> snaphash_sha512_buffers -> digests on the host, every rank its LPT shard of the ONE tree "
+                   "over its own PCIe link (pinned staging on the GPU's NUMA node, H2D, kernels); barrier to barrier, MAX over ranks",
+           "n_gpus": world, "ms": round(dt * 1e3, 2), "GiBps": round(total_bytes / 2**30 / dt, 2),
+           "h2d_ms": round(st["h2d_ms"], 2), "kernel_ms": round(st["kernel_ms"], 2), "launches": int(st["launches"]),
+           "per_rank": per_rank, "every_byte_on_the_gpu": True,
+           "parity": "every rank's digest vector identical to its HBM-resident pass", "best_of": 3}
+    return out
+
+
+def e2e_package(total_mib=512):
+    """A package as `snappy build` meets it: a tree and, beside it, an archive of the tree's own size (the stand-in
+    for its data.tar.gz, snappy/build.go:222) through snaphash_tree in the library's DEFAULT configuration -- the
+    archive is ONE stream, so the default hands it to a host thread while the GPU takes the tree.  hashes.yaml is
+    compared with the oracle's."""
+    from oracle import oracle
+    from snappy_amd import Context, synthetic
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    if base and shutil.disk_usage(base).free < (total_mib << 20) * 2 + (1 << 30):
+        total_mib = max(32, int((shutil.disk_usage(base).free - (1 << 30)) // (2 << 20)))
+    tmp = tempfile.mkdtemp(prefix="snaphash_pkg_", dir=base)
+    try:
+        build = os.path.join(tmp, "build")
+        rng = np.random.default_rng(9)
+        blob = rng.integers(0, 256, size=(2 << 20) + 64, dtype=np.uint8).tobytes()
+        for i in range(total_mib):
+            p = os.path.join(build, synthetic.file_name(i))
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            with open(p, "wb") as f:
+                f.write(blob[i % 4096:(i % 4096) + (1 << 20)])
+        tar = os.path.join(tmp, "data.tar.gz")
+        with open(tar, "wb") as f:
+            for i in range(total_mib):
+                f.write(blob[(7 * i) % 4096:((7 * i) % 4096) + (1 << 20)])
+        with Context(flags=0) as c:  # the defaults a cgo caller gets from snaphash_init(NULL)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                y = c.tree(build, tar)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, c.stats(), c.stats_ex())
+        dt, st, ex = best
+        t0 = time.perf_counter()
+        want = oracle.hashes_yaml(build, tar)
+        dt_c = time.perf_counter() - t0
+        if want != y:
+            raise SystemExit("PARITY FAILURE: package leg: hashes.yaml differs from the oracle's")
+        total = 2 * (total_mib << 20)
+        return {"what": "%d x 1 MiB tree (tmpfs) + a %d MiB archive beside it -> snaphash_tree, DEFAULT configuration "
+                        "(snaphash_init(NULL)): the archive, one stream, on a host thread; the tree on the GPU" % (total_mib, total_mib),
+                "bytes": total, "ms": round(dt * 1e3, 1), "GiBps": round(total / 2**30 / dt, 2),
+                "gpu_bytes": int(ex["gpu_bytes"]), "host_bytes": int(ex["host_bytes"]), "host_streams": int(ex["host_streams"]),
+                "host_ms": round(ex["host_ms"], 1), "kernel_ms": round(st["kernel_ms"], 1),
+                "cpu_port_serial_ms": round(dt_c * 1e3, 1),
+                "parity": "hashes.yaml byte-identical to the oracle's", "best_of": 3}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def e2e_tree(ctx, host, offsets, lens, nfiles, cpu_seconds):
@@ -212,6 +277,24 @@ def e2e_tree(ctx, host, offsets, lens, nfiles, cpu_seconds):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def deflate_roofline(zs):
+    """roofline object of deflate_chunks_kernel (+ the concatenation kernel: deflate_ms is both): algorithmic bytes =
+    tar bytes read + gz bytes written, over the kernels' HIP-event time; counter traffic from the profile of the same
+    workload when one is committed (profiles/traffic_deflate_chunks_kernel.json)."""
+    alg = zs["tar_bytes"] + zs["gz_bytes"]
+    ach = alg / (zs["deflate_ms"] * 1e-3) / 1e9
+    traffic, src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_deflate_chunks_kernel.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("tar_bytes") == zs["tar_bytes"]:
+            traffic, src = tj.get("hbm_bytes_total"), os.path.relpath(tpath, ROOT)
+    return {"bound": "hbm", "kernel": "deflate_chunks_kernel (+ deflate_compact_kernel)", "achieved": round(ach, 2),
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "algorithmic_bytes": int(alg),
+            "traffic": traffic, "traffic_source": src, "GBps_of_input": round(zs["tar_bytes"] / (zs["deflate_ms"] * 1e-3) / 1e9, 2),
+            "note": "algorithmic bytes = input read + output written; instruction- and LDS-latency-bound (DESIGN.md sec. 9)"}
+
+
 def e2e_build(ctx, total_mib=1024):
     """Rows f2 + f3: `Build`'s data step in one pass -- data.tar.gz (GPU DEFLATE) + archive digest + per-file SHA-512
     + hashes.yaml, every file read once -- on a compressible tree (Zipf-word text, 1 MiB files); the archive is read
@@ -257,10 +340,7 @@ def e2e_build(ctx, total_mib=1024):
                 "tar_bytes": int(zs["tar_bytes"]), "gz_bytes": int(zs["gz_bytes"]), "ratio": round(zs["gz_bytes"] / zs["tar_bytes"], 4),
                 "ms": round(dt * 1e3, 1), "GiBps_of_tree": round(zs["tar_bytes"] / 2**30 / dt, 2),
                 "deflate_kernel_ms": round(zs["deflate_ms"], 1), "sha512_kernel_ms": round(st["kernel_ms"], 1),
-                "deflate_kernel": {"GBps_of_input": round(zs["tar_bytes"] / (zs["deflate_ms"] * 1e-3) / 1e9, 2),
-                                   "frac_of_hbm_peak": round(zs["tar_bytes"] / (zs["deflate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                                   "note": "algorithmic bytes = input bytes; instruction- and LDS-latency-bound, sized to hide "
-                                           "behind the archive digest (DESIGN.md sec. 9)"},
+                "deflate_kernel": deflate_roofline(zs),
                 "bound": "the serial SHA-512 of the archive on one host core (DESIGN.md sec. 9)",
                 "parity": "archive inflates to the tree (tarfile); archive digest = hashlib; hashes.yaml byte-identical to the oracle's",
                 "best_of": 3}
@@ -357,26 +437,6 @@ def main():
                     "ms_per_step": round(j2["elapsed"] / nrep * 1e3, 4), "steps": nrep}
         del j2
 
-    # ---- N > 1: the same tree through ONE process and the C ABI's device list (what the Go caller reaches over
-    # cgo): in-library LPT shards + single-process RCCL gather.  A child process with a time limit: the headline
-    # line never depends on it. ----------------------------------------------------------------------------------
-    inlib = None
-    if world > 1 and rank == 0 and os.environ.get("SNAPHASH_BENCH_NO_INLIB") != "1" and args.workload in ("C1", "C2", "C5"):
-        import subprocess
-        try:
-            env = dict(os.environ)
-            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK",
-                      "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE"):
-                env.pop(k, None)
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "inlib_multigpu.py"), args.workload, "-1"],
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, env=env)
-            lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
-            inlib = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
-        except Exception as e:  # a time-out or a missing RCCL must not cost the headline
-            inlib = {"error": repr(e)[:400]}
-    if use_dist:
-        dist.barrier()
-
     # ---- parity spot check of the timed path, outside the timed region ------------------
     digests = job["digests"]
     parity = None
@@ -391,43 +451,66 @@ def main():
         parity = {"checked_files": len(sample), "result": "bit-exact vs hashlib.sha512",
                   "sha512_of_digest_vector": hashlib.sha512(digests.tobytes()).hexdigest()[:32]}
 
-    # ---- end-to-end legs and the CPU baseline: rank 0, N = 1 only -------------------------
+    # ---- end-to-end legs ------------------------------------------------------------------
+    # every N: each rank hashes its shard from host memory over its own PCIe link (the rate that shards);
+    # N = 1 also: on-disk tree, package (default configuration), fused build; and the CPU baseline.
     end_to_end, cpu = None, None
-    if rank == 0 and world == 1 and not force_dist:
-        mode = args.e2e
-        if mode == "auto":
-            mode = "full" if args.workload == "C2" else ("buffers" if job["total_bytes"] <= (16 << 30) else "off")
-        if mode != "off":
-            host = job["data"].cpu().numpy()  # the same bytes the resident pass hashed, now in host memory
-            del job["data"]
-            torch.cuda.empty_cache()
-            ectx = Context(device=local_rank, kernel=kern)  # own stream and staging engine
-            end_to_end = {}
+    mode = args.e2e
+    if mode == "auto":
+        mode = "full" if args.workload == "C2" else ("buffers" if job["total_bytes"] <= (16 << 30) else "off")
+    if force_dist and world == 1 and mode == "full":
+        mode = "buffers"
+    if mode != "off":
+        host = job["data"].cpu().numpy()  # the same bytes the resident pass hashed, now in this rank's host memory
+        del job["data"]
+        torch.cuda.empty_cache()
+        ectx = Context(device=local_rank, kernel=kern, flags=_lib.FLAG_GPU_ONLY)  # own stream and staging engine
+        end_to_end = {}
 
-            def leg(name, fn):
-                # an auxiliary leg that cannot run here (no room in /dev/shm, ...) is recorded, it never costs the headline
-                # line; a PARITY FAILURE is a SystemExit and still ends the run
-                try:
-                    return fn()
-                except Exception as e:  # noqa: BLE001
-                    end_to_end[name] = {"error": repr(e)[:300]}
-                    return None
-            r = leg("buffers", lambda: e2e_buffers(ectx, host, job["my_off"], job["my_lens"], digests))
+        def allmax(x):
+            if not use_dist:
+                return x
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        def gather(obj):
+            if not use_dist:
+                return [obj]
+            objs = [None] * world
+            dist.all_gather_object(objs, obj)
+            return objs
+        mine = ShardPlan(sizes, world).members(rank)
+        local_want = digests[mine] if len(mine) else digests[:0]
+        r = e2e_buffers_sharded(ectx, host, job["my_off"], job["my_lens"], local_want, job["total_bytes"], world, fence, allmax, gather)
+        end_to_end["buffers_sharded"] = r
+        if world == 1:
+            end_to_end["buffers"] = {k: v for k, v in r.items() if k != "per_rank"}  # the name round 2 reported this leg under
+
+        def leg(name, fn):
+            # an auxiliary leg that cannot run here (no room in /dev/shm, ...) is recorded, it never costs the headline
+            # line; a PARITY FAILURE is a SystemExit and still ends the run
+            try:
+                return fn()
+            except Exception as e:  # noqa: BLE001
+                end_to_end[name] = {"error": repr(e)[:300]}
+                return None
+        if rank == 0 and world == 1 and mode == "full":
+            r = leg("tree", lambda: e2e_tree(ectx, host, job["my_off"], job["my_lens"], args.e2e_files, args.cpu_seconds))
             if r is not None:
-                end_to_end["buffers"] = r
-            if mode == "full":
-                r = leg("tree", lambda: e2e_tree(ectx, host, job["my_off"], job["my_lens"], args.e2e_files, args.cpu_seconds))
-                if r is not None:
-                    end_to_end["tree"], cpu = r
-                r = leg("build", lambda: e2e_build(ectx))
-                if r is not None:
-                    end_to_end["build"] = r
-            ectx.close()
+                end_to_end["tree"], cpu = r
             del host
-        if args.cpu_seconds > 0:
-            if cpu is None:
-                cpu = cpu_baseline_buffers(tree, args.cpu_seconds)
-            cpu["all_cores"] = cpu_pool_leg(tree, 3.0)
+            r = leg("package", e2e_package)
+            if r is not None:
+                end_to_end["package"] = r
+            r = leg("build", lambda: e2e_build(ectx))
+            if r is not None:
+                end_to_end["build"] = r
+        ectx.close()
+    if rank == 0 and world == 1 and not force_dist and args.cpu_seconds > 0:
+        if cpu is None:
+            cpu = cpu_baseline_buffers(tree, args.cpu_seconds)
+        cpu["all_cores"] = cpu_pool_leg(tree, 3.0)
 
     if rank == 0:
         st = job["stats"]
@@ -452,7 +535,8 @@ def main():
                       else "GiB/s hashed (whole node), bit-exact hashes.yaml, workload %s x%d" % (args.workload, ntrees),
             "value": round(value, 3), "unit": "GiB/s",
             "value_kind": "hbm_resident: file bytes already in HBM when the timed region starts; kernels + digest gather "
-                          "only (PCIe- and disk-inclusive rates: end_to_end)",
+                          "only.  This job is stream-count-bound and flat in N by construction (DESIGN.md sec. 5); the rate "
+                          "that scales with N is end_to_end.buffers_sharded (host memory -> N PCIe links -> digests)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -472,19 +556,36 @@ def main():
         }
         if side_leg is not None:
             line["other_scaling_leg"] = side_leg
-        if inlib is not None:
-            if "sha512_of_digest_vector" in inlib:
-                inlib["same_digest_vector_as_the_timed_path"] = inlib["sha512_of_digest_vector"] == parity["sha512_of_digest_vector"]
-            line["in_library_multi_gpu"] = inlib
         if end_to_end is not None:
             line["end_to_end"] = end_to_end
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
     ctx.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # ---- N > 1: the same tree through ONE process and the C ABI's device list (what the Go caller reaches over
+        # cgo): in-library LPT shards, one NUMA-placed staging engine per GPU, single-process RCCL gather.  Run when
+        # the ranks have let go of their GPUs, in a child process with a time limit: the line never depends on it. ----
+        if world > 1 and os.environ.get("SNAPHASH_BENCH_NO_INLIB") != "1" and args.workload in ("C1", "C2", "C5"):
+            import subprocess
+            torch.cuda.empty_cache()
+            try:
+                env = dict(os.environ)
+                for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK",
+                          "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE"):
+                    env.pop(k, None)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "inlib_multigpu.py"), args.workload, "-1"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, env=env)
+                lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+                inlib = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
+            except Exception as e:  # a time-out or a missing RCCL must not cost the headline
+                inlib = {"error": repr(e)[:400]}
+            if "sha512_of_digest_vector" in inlib:
+                inlib["same_digest_vector_as_the_timed_path"] = inlib["sha512_of_digest_vector"] == parity["sha512_of_digest_vector"]
+            line["in_library_multi_gpu"] = inlib
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SNAPHASH_ABI_VERSION 2
+#define SNAPHASH_ABI_VERSION 3
 
 enum {
     SNAPHASH_OK = 0,
@@ -72,8 +72,12 @@ enum { /* snaphash_config.flags */
     SNAPHASH_FLAG_CHECK_GATHER = 1, /* several devices: also copy every device's digest slab to the host and
                                        require the RCCL-gathered vector to equal it (the collective's parity check) */
     SNAPHASH_FLAG_NO_RCCL = 2,      /* several devices: gather by per-device copies only */
-    SNAPHASH_FLAG_FORCE_GATHER = 4  /* run the gather (RCCL with one rank) even on a single-device ctx: lets a
+    SNAPHASH_FLAG_FORCE_GATHER = 4, /* run the gather (RCCL with one rank) even on a single-device ctx: lets a
                                        1-GPU box exercise the collective path */
+    /* ---- ABI 3 ---- */
+    SNAPHASH_FLAG_GPU_ONLY = 8,     /* every byte of every stream is hashed by the HIP kernels, whatever it costs (the
+                                       roofline runs and the parity tests of the kernels); host_threads is ignored */
+    SNAPHASH_FLAG_NO_NUMA = 16      /* do not place staging memory and fill threads on the GPU's NUMA node */
 };
 
 typedef struct snaphash_config {
@@ -89,11 +93,18 @@ typedef struct snaphash_config {
                                (two engines on one GPU: used by the tests on a 1-GPU box; RCCL needs distinct
                                devices, so the gather then falls back to per-device copies). */
     uint32_t n_devices;     /* 0 = the single `device` above */
-    uint32_t host_threads;  /* hybrid scheduling, opt-in: > 0 lets the library hash on that many host threads,
-                               concurrently with the GPU batch, the few streams whose single-stream time on the
-                               GPU would set the makespan (a lone stream advances at ~40 MB/s on the GPU, ~0.5 GB/s
-                               on a host core).  0 (default) = every byte is hashed on the GPU.  Not a fallback:
-                               init still fails without a gfx950 device.  Host entry points only. */
+    uint32_t host_threads;  /* hybrid scheduling (host entry points only).  A lone SHA-512 stream advances at ~45 MB/s
+                               on the GPU whatever surrounds it and at ~1.4 GB/s on a host core (the library's own
+                               vectorised SHA-512, hostsha.cpp), so a stream that would set the makespan of its batch
+                               all by itself -- the package's data.tar.gz (build.go:222), a 1 GiB member -- is hashed
+                               on a host thread, concurrently with the GPU batch.
+                                 0 (default, ABI 3) = automatic: min(12, cores) threads, and ONLY streams whose own GPU
+                                     time exceeds that of the whole rest of the batch are moved;
+                                 N > 0 = N threads and the full planner: streams move while that shortens the modelled
+                                     makespan max(GPU, host);
+                                 SNAPHASH_FLAG_GPU_ONLY = none (what 0 meant in ABI 2).
+                               snaphash_stats_ex says which bytes went where.  Not a fallback: init still fails
+                               without a gfx950 device. */
     uint32_t flags;         /* SNAPHASH_FLAG_* */
     uint32_t reserved2;
 } snaphash_config;
@@ -116,17 +127,18 @@ typedef struct snaphash_stats_ex { /* of the most recent hashing call on the ctx
     uint32_t gather_checked; /* 1 = the RCCL result was compared with per-device copies and matched */
     double gather_ms;      /* digest gather, host clock */
     uint64_t gpu_bytes;    /* bytes hashed by HIP kernels */
-    uint64_t host_bytes;   /* bytes hashed by host threads (hybrid scheduling; 0 unless host_threads > 0) */
-    uint64_t host_streams; /* streams that finished on a host thread */
-    uint64_t handover_streams; /* of those, streams whose prefix was hashed on the GPU first */
+    uint64_t host_bytes;   /* bytes hashed by host threads (hybrid scheduling; always 0 with SNAPHASH_FLAG_GPU_ONLY) */
+    uint64_t host_streams; /* streams that were hashed on a host thread */
+    uint64_t reserved3;    /* (ABI 2 declared a mid-stream hand-over counter here that was never implemented: whole
+                              streams move or none) */
     double host_ms;        /* busiest host thread, host clock */
 } snaphash_stats_ex;
 
 /* ---- lifetime -------------------------------------------------------------- */
 /* cfg == NULL: the calling thread's current device, defaults throughout -- unless the environment says otherwise
  * (the reference's build has neither config file nor flags for this): SNAPHASH_DEVICES = "all" or
- * "0,1,..." names the engines, SNAPHASH_HOST_THREADS = N turns hybrid scheduling on.  A non-NULL cfg is taken as
- * it is; the environment is not consulted. */
+ * "0,1,..." names the engines, SNAPHASH_HOST_THREADS = N sets the hybrid scheduler's threads (0 = none: every
+ * byte on the GPU).  A non-NULL cfg is taken as it is; the environment is not consulted. */
 int snaphash_init(const snaphash_config *cfg /* may be NULL */, snaphash_ctx **out);
 void snaphash_destroy(snaphash_ctx *ctx);
 int snaphash_abi_version(void);
@@ -200,7 +212,8 @@ void snaphash_free(void *p);
  * staging buffers go to the GPU while the producer keeps reading; a stream's chaining value
  * stays in HBM between launches.  Streams are numbered 0 .. n_streams-1 by the caller.
  * finish pads and hashes what is left and writes n_streams digests (a stream that was never
- * appended to hashes as the empty file; a stream not ended is ended).  Single-device ctx only. */
+ * appended to hashes as the empty file; a stream not ended is ended).  On a ctx with several devices the batch
+ * runs on the first engine (a producer that feeds one chunk at a time is one PCIe link's worth of work at most). */
 typedef struct snaphash_batch snaphash_batch;
 int snaphash_batch_begin(snaphash_ctx *ctx, size_t n_streams, snaphash_batch **out);
 int snaphash_batch_append(snaphash_batch *b, size_t stream, const void *data, size_t n);
@@ -232,7 +245,9 @@ typedef struct snaphash_targz_stats { /* of the most recent snaphash_tar_create 
  * yaml_out != NULL fuses writeHashes into the same pass (row f2: every file is read ONCE): the SHA-512
  * kernels hash each regular file out of the staged tar stream, the archive digest is taken over the
  * bytes written, and *yaml_out receives hashes.yaml (snaphash_free); exclude_prefix must then be
- * writeHashes' own rule.  archive_digest (may be NULL): the 64 raw bytes of SHA-512(tarname). */
+ * writeHashes' own rule.  archive_digest (may be NULL): the 64 raw bytes of SHA-512(tarname).
+ * On a ctx with several devices the producer runs on the first engine: the pass is bound by the one stream that
+ * cannot be split -- the SHA-512 of the archive on a host core, 1.4 GB/s -- which a single PCIe link outruns 40x. */
 int snaphash_tar_create(snaphash_ctx *ctx, const char *tarname, const char *source_dir, const char *exclude_prefix,
                         char **yaml_out, size_t *yaml_len, uint8_t *archive_digest);
 
@@ -253,7 +268,8 @@ void snaphash_get_targz_stats(const snaphash_ctx *ctx, snaphash_targz_stats *out
 
 /* helpers.FilesAreEqual (helpers/cmp.go:31-60), batched: equal[i] = 1 iff a[i] and b[i] both
  * open, have the same size and the same bytes; as upstream, any open/stat/read error makes the
- * pair "not equal" (it is not an error of the call).  The bytes are compared on the GPU. */
+ * pair "not equal" (it is not an error of the call).  The bytes are compared on the GPU; a ctx with several
+ * devices deals the pairs to its engines (LPT by size), each over its own PCIe link. */
 int snaphash_files_equal(snaphash_ctx *ctx, const char *const *a, const char *const *b, size_t n,
                          uint8_t *equal);
 
@@ -327,6 +343,29 @@ void snaphash_get_stats(const snaphash_ctx *ctx, snaphash_stats *out); /* severa
 int snaphash_get_stats_ex(const snaphash_ctx *ctx, snaphash_stats_ex *out);
 /* per engine i < n_devices: its HIP ordinal and its own stats of the most recent call */
 int snaphash_get_device_stats(const snaphash_ctx *ctx, uint32_t i, int32_t *device, snaphash_stats *out);
+
+/* ---- ABI 3: where an engine's staging lives -------------------------------------------------------------
+ * One engine per GPU moves ~55 GB/s over its own PCIe link; on a two-socket node the pinned staging buffers and
+ * the threads that fill them belong on the socket the GPU hangs off.  snaphash_init reads the GPU's NUMA node
+ * from sysfs (/sys/bus/pci/devices/<bdf>/numa_node), allocates the engine's pinned memory there and binds the
+ * engine's fill threads to that node's CPUs; a ctx with several engines divides the CPUs it may use among them.
+ * Nothing in the reference corresponds to this (its pass is one goroutine, snappy/build.go:228). */
+typedef struct snaphash_engine_info {
+    uint32_t struct_size;  /* in: sizeof(snaphash_engine_info) */
+    int32_t device;        /* HIP ordinal */
+    int32_t numa_node;     /* the GPU's node as sysfs reports it; -1 = unknown, single-node host or SNAPHASH_FLAG_NO_NUMA */
+    int32_t staging_node;  /* node the engine's first pinned staging page was found on; -1 = not allocated yet / unknown */
+    uint32_t fill_threads; /* most staging-fill threads the engine uses at a time */
+    uint32_t n_cpus;       /* CPUs of numa_node the fill threads are bound to (0 = not bound) */
+    char pci_bus_id[32];
+} snaphash_engine_info;
+int snaphash_get_engine_info(const snaphash_ctx *ctx, uint32_t i, snaphash_engine_info *out);
+
+/* Host-only: the topology probe the engines use, on any sysfs tree (the tests hand in a fake one).  *node = NUMA node
+ * of the PCI function (-1 unknown); cpus (may be NULL) receives up to cap CPU numbers of that node, *n_cpus how many
+ * the node has. */
+int snaphash_numa_probe(const char *sysfs_root, const char *pci_bus_id, int32_t *node, int32_t *cpus, size_t cap,
+                        size_t *n_cpus);
 
 #ifdef __cplusplus
 }

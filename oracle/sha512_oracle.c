@@ -20,9 +20,10 @@
  * The arithmetic itself lives outside /root/reference: Go's standard library
  * crypto/sha512 (Go version unpinned, debian/control:11 says golang-go).  Its
  * published algorithm is FIPS 180-4 sec. 5.1.2 / 6.4, restated here.  YAML bytes
- * come from gopkg.in/yaml.v2 @ 49c95bdc (dependencies.tsv:7); only the
- * plain-scalar layout pinned by snappy/hashes_test.go:89-103 is restated and
- * names outside a conservative plain-safe set are refused.
+ * come from gopkg.in/yaml.v2 @ 49c95bdc (dependencies.tsv:7): the layout is
+ * pinned by snappy/hashes_test.go:89-103 for plain names; quoted and folded
+ * names follow the library's published algorithm (name_scalar below) and are
+ * PARITY UNPINNED -- no reference fixture holds one.
  *
  * Parity pinning: checked in tests/test_oracle.py against the reference's own
  * known answers (helpers/helpers_test.go:175, snappy/hashes_test.go:30-33 and
@@ -37,6 +38,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -222,29 +224,198 @@ int oracle_mode_string(unsigned st_mode, char out[11])
     return 0;
 }
 
-/* Names that yaml.v2 is known to emit as plain scalars (the only case the
- * reference pins).  Anything else is refused: ORACLE_EUNSAFE. */
-static int plain_safe_name(const char *s)
+/* The value of `name:` as gopkg.in/yaml.v2 @ 49c95bdc writes a Go string (snappy/build.go:249-264 marshals every
+ * file name).  The library is not in the reference tree: its published algorithm is restated -- resolve.go (a text
+ * that would read back as bool/null/int/float is double-quoted; so are base-60 floats, encode.go isBase60Float),
+ * emitterc.go yaml_emitter_analyze_scalar / select_scalar_style / the three scalar writers (the libyaml port: plain
+ * unless indicators, leading or trailing space forbid it in block context, then single-quoted, double-quoted when a
+ * character is not printable; lines fold at a space past column 80, continuation indented by 4).
+ * PARITY UNPINNED: the reference's fixtures hold plain names only (snappy/hashes_test.go:89-103).
+ * Returns 0, or -1 for what is not restated (invalid UTF-8 -> !!binary, line breaks, spellings whose type depends on
+ * the Go release: 0o17, hex floats, "<<"). */
+static int nm_digit(int c) { return c >= '0' && c <= '9'; }
+static int nm_hex(int c) { return nm_digit(c) || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F'); }
+static int nm_ieq(const char *s, const char *t) { return strcasecmp(s, t) == 0; }
+
+static int nm_float(const char *s) /* strconv.ParseFloat, decimal grammar + inf/infinity/nan */
 {
-    size_t n = strlen(s);
-    if (n == 0 || n > 1000) return 0;
-    int alpha = 0;
-    for (size_t i = 0; i < n; i++) {
-        unsigned char c = (unsigned char)s[i];
-        int ok = (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') ||
-                 c == '_' || c == '.' || c == '/' || c == '-' || c == '+';
-        if (!ok) return 0;
+    const char *p = s;
+    if (*p == '+' || *p == '-') { if (nm_ieq(p + 1, "inf") || nm_ieq(p + 1, "infinity")) return 1; p++; }
+    else if (nm_ieq(p, "inf") || nm_ieq(p, "infinity") || nm_ieq(p, "nan")) return 1;
+    int nd = 0;
+    while (nm_digit(*p)) { p++; nd++; }
+    if (*p == '.') { p++; while (nm_digit(*p)) { p++; nd++; } }
+    if (!nd) return 0;
+    if (*p == 'e' || *p == 'E') {
+        p++;
+        if (*p == '+' || *p == '-') p++;
+        if (!nm_digit(*p)) return 0;
+        while (nm_digit(*p)) p++;
     }
-    unsigned char c0 = (unsigned char)s[0];
-    if (c0 == '-' || c0 == '.' || c0 == '+' || (c0 >= '0' && c0 <= '9')) return 0; /* may resolve as number/indicator */
-    for (size_t i = 0; i < n; i++)
-        if ((s[i] >= 'a' && s[i] <= 'z') || (s[i] >= 'A' && s[i] <= 'Z')) alpha = 1;
-    if (!alpha) return 0;
-    static const char *const resolved[] = {"y", "Y", "yes", "Yes", "YES", "on", "On", "ON", "n", "N", "no", "No", "NO",
-        "off", "Off", "OFF", "true", "True", "TRUE", "false", "False", "FALSE", "null", "Null", "NULL", 0};
-    for (int i = 0; resolved[i]; i++)
-        if (!strcmp(s, resolved[i])) return 0;
+    return *p == 0;
+}
+static int nm_int(const char *s) /* ParseInt/ParseUint base 0 syntax (a range error still ends as a float) */
+{
+    if (*s == '+' || *s == '-') s++;
+    if (!*s) return 0;
+    if (s[0] == '0' && (s[1] == 'x' || s[1] == 'X')) { s += 2; if (!*s) return 0; while (nm_hex(*s)) s++; return *s == 0; }
+    while (nm_digit(*s)) s++;
+    return *s == 0;
+}
+static int nm_bin(const char *s) /* resolve.go: 0b / -0b */
+{
+    if (*s == '-') s++;
+    if (s[0] != '0' || s[1] != 'b' || !s[2]) return 0;
+    for (s += 2; *s; s++) if (*s != '0' && *s != '1') return 0;
     return 1;
+}
+static int nm_version_dependent(const char *s)
+{
+    const char *q = s;
+    if (*q == '+' || *q == '-') q++;
+    if (q[0] != '0' || !q[1] || !q[2]) return 0;
+    if (q[1] == 'o' || q[1] == 'O') { for (q += 2; *q; q++) if (*q < '0' || *q > '7') return 0; return 1; }
+    if (q[1] == 'x' || q[1] == 'X') {
+        int has_p = 0;
+        for (q += 2; *q; q++) {
+            if (*q == 'p' || *q == 'P') has_p = 1;
+            else if (!nm_hex(*q) && *q != '.' && *q != '+' && *q != '-') return 0;
+        }
+        return has_p;
+    }
+    if (q[1] == 'b' || q[1] == 'B') {
+        if (nm_bin(s)) return 0;
+        for (q += 2; *q; q++) if (*q != '0' && *q != '1') return 0;
+        return 1;
+    }
+    return 0;
+}
+static int nm_base60(const char *s)
+{
+    if (!(*s == '+' || *s == '-' || nm_digit(*s)) || !strchr(s, ':')) return 0;
+    if (*s == '+' || *s == '-') s++;
+    if (!nm_digit(*s)) return 0;
+    s++;
+    while (nm_digit(*s) || *s == '_') s++;
+    int groups = 0;
+    while (*s == ':') {
+        s++;
+        if (*s >= '0' && *s <= '5' && nm_digit(s[1])) s += 2;
+        else if (nm_digit(*s)) s += 1;
+        else return 0;
+        groups++;
+    }
+    if (!groups) return 0;
+    if (*s == '.') { s++; while (nm_digit(*s) || *s == '_') s++; }
+    return *s == 0;
+}
+/* 1: resolves to another type than !!str; 0: a string; -1: not restated */
+static int nm_resolves(const char *s)
+{
+    static const char *const mapped[] = {"y", "Y", "yes", "Yes", "YES", "on", "On", "ON", "n", "N", "no", "No", "NO", "off",
+        "Off", "OFF", "true", "True", "TRUE", "false", "False", "FALSE", "~", "null", "Null", "NULL", ".nan", ".NaN", ".NAN",
+        ".inf", ".Inf", ".INF", "+.inf", "+.Inf", "+.INF", "-.inf", "-.Inf", "-.INF", 0};
+    int c0 = (unsigned char)s[0];
+    int hm = c0 && strchr("yYnNtTfFoO~", c0) != 0, hn = c0 == '+' || c0 == '-' || nm_digit(c0), hd = c0 == '.';
+    if (!hm && !hn && !hd) return strcmp(s, "<<") == 0 ? -1 : 0;
+    for (int i = 0; mapped[i]; i++) if (!strcmp(s, mapped[i])) return 1;
+    if (hm) return 0;
+    if (hd) return nm_float(s);
+    char plain[4200];
+    size_t k = 0;
+    for (const char *p = s; *p && k + 1 < sizeof plain; p++) if (*p != '_') plain[k++] = *p;
+    plain[k] = 0;
+    if (nm_version_dependent(plain)) return -1;
+    return nm_int(plain) || nm_float(plain) || nm_bin(plain);
+}
+static int nm_decode(const unsigned char *p, uint32_t *cp) /* bytes of the well-formed UTF-8 sequence at p, 0 if none */
+{
+    if (p[0] < 0x80) { *cp = p[0]; return 1; }
+    if (p[0] >= 0xC2 && p[0] <= 0xDF && (p[1] & 0xC0) == 0x80) { *cp = ((p[0] & 0x1Fu) << 6) | (p[1] & 0x3Fu); return 2; }
+    if (p[0] >= 0xE0 && p[0] <= 0xEF && (p[1] & 0xC0) == 0x80 && (p[2] & 0xC0) == 0x80) {
+        uint32_t v = ((p[0] & 0x0Fu) << 12) | ((p[1] & 0x3Fu) << 6) | (p[2] & 0x3Fu);
+        if (v < 0x800 || (v >= 0xD800 && v <= 0xDFFF)) return 0;
+        *cp = v; return 3;
+    }
+    if (p[0] >= 0xF0 && p[0] <= 0xF4 && (p[1] & 0xC0) == 0x80 && (p[2] & 0xC0) == 0x80 && (p[3] & 0xC0) == 0x80) {
+        uint32_t v = ((p[0] & 0x07u) << 18) | ((p[1] & 0x3Fu) << 12) | ((p[2] & 0x3Fu) << 6) | (p[3] & 0x3Fu);
+        if (v < 0x10000 || v > 0x10FFFF) return 0;
+        *cp = v; return 4;
+    }
+    return 0;
+}
+static int nm_printable(uint32_t c)
+{
+    return c == 0x0A || (c >= 0x20 && c <= 0x7E) || (c >= 0xA0 && c <= 0xD7FF) || (c >= 0xE000 && c <= 0xFFFD && c != 0xFEFF);
+}
+typedef struct { sbuf *out; int col; } nm_emit;
+static void nm_put(nm_emit *e, char c) { sb_put(e->out, &c, 1); e->col++; }
+static void nm_fold(nm_emit *e) { sb_puts(e->out, "\n    "); e->col = 4; }
+
+static int name_scalar(sbuf *out, const char *s)
+{
+    size_t len = strlen(s);
+    if (len == 0 || len > 4096) return -1;
+    uint32_t cp[4100]; unsigned char w[4100]; size_t n = 0;
+    for (size_t i = 0; i < len;) {
+        uint32_t c; int k = nm_decode((const unsigned char *)s + i, &c);
+        if (!k || c == '\n' || c == '\r' || c == 0x85 || c == 0x2028 || c == 0x2029) return -1;
+        cp[n] = c; w[n] = (unsigned char)k; n++; i += (size_t)k;
+    }
+    int res = nm_resolves(s);
+    if (res < 0) return -1;
+    int style = (res == 1 || nm_base60(s)) ? 2 : 0; /* 0 plain, 1 single, 2 double */
+    int block_ind = len >= 3 && (!strncmp(s, "---", 3) || !strncmp(s, "...", 3));
+    int special = 0, lead = 0, trail = 0, prev_ws = 1;
+    for (size_t k = 0; k < n; k++) {
+        uint32_t c = cp[k];
+        int next_ws = k + 1 >= n || cp[k + 1] == ' ' || cp[k + 1] == '\t';
+        if (k == 0) {
+            if (c && c < 0x80 && strchr("#,[]{}&*!|>'\"%@`", (int)c)) block_ind = 1;
+            else if ((c == '?' || c == ':' || c == '-') && next_ws) block_ind = 1;
+        } else if ((c == ':' && next_ws) || (c == '#' && prev_ws)) block_ind = 1;
+        if (!nm_printable(c)) special = 1;
+        if (c == ' ') { if (k == 0) lead = 1; if (k + 1 == n) trail = 1; }
+        prev_ws = c == ' ' || c == '\t';
+    }
+    if (style == 0 && (lead || trail || special || block_ind)) style = 1;
+    if (style == 1 && special) style = 2;
+    nm_emit e = {out, 7}; /* behind "- name:" */
+    nm_put(&e, ' ');
+    if (style == 1) nm_put(&e, '\'');
+    if (style == 2) nm_put(&e, '"');
+    int spaces = 0;
+    size_t bi = 0;
+    for (size_t k = 0; k < n; bi += w[k], k++) {
+        uint32_t c = cp[k];
+        if (style == 2 && (!nm_printable(c) || c == 0xFEFF || c == '"' || c == '\\')) {
+            nm_put(&e, '\\');
+            const char *esc = c == 0 ? "0" : c == 7 ? "a" : c == 8 ? "b" : c == 9 ? "t" : c == 0xB ? "v" : c == 0xC ? "f" :
+                              c == 0xD ? "r" : c == 0x1B ? "e" : c == '"' ? "\"" : c == '\\' ? "\\" : 0;
+            if (esc) nm_put(&e, esc[0]);
+            else {
+                int digits = c <= 0xFF ? 2 : c <= 0xFFFF ? 4 : 8;
+                nm_put(&e, digits == 2 ? 'x' : digits == 4 ? 'u' : 'U');
+                for (int sh = (digits - 1) * 4; sh >= 0; sh -= 4) nm_put(&e, "0123456789ABCDEF"[(c >> sh) & 15]);
+            }
+            spaces = 0;
+        } else if (c == ' ') {
+            int fold = !spaces && e.col > 80;
+            if (style == 0) fold = fold && !(k + 1 < n && cp[k + 1] == ' ');
+            else if (style == 1) fold = fold && k > 0 && k + 1 < n && cp[k + 1] != ' ';
+            else fold = fold && k > 0 && k + 1 < n;
+            if (fold) { nm_fold(&e); if (style == 2 && cp[k + 1] == ' ') nm_put(&e, '\\'); }
+            else nm_put(&e, ' ');
+            spaces = 1;
+        } else {
+            if (style == 1 && c == '\'') nm_put(&e, '\'');
+            sb_put(out, s + bi, w[k]); e.col++;
+            spaces = 0;
+        }
+    }
+    if (style == 1) nm_put(&e, '\'');
+    if (style == 2) nm_put(&e, '"');
+    return 0;
 }
 
 enum { ORACLE_OK = 0, ORACLE_EIO = -1, ORACLE_EMODE = -2, ORACLE_EUNSAFE = -3, ORACLE_ENOMEM = -4 };
@@ -257,34 +428,26 @@ static int cmp_names(const void *a, const void *b)
 }
 
 /* path/filepath.Walk as writeHashes uses it (snappy/build.go:228-259). */
+static void visit(walkst *w, const char *path, const struct stat *stp);
+
 static void walk(walkst *w, const char *path)
 {
     struct stat st;
     if (w->err) return;
     if (lstat(path, &st) != 0) { w->err = ORACLE_EIO; w->saved_errno = errno; return; }
-    const char *rel = path + w->rootlen;
-    int skip = (strncmp(rel, "/DEBIAN", 7) == 0) || rel[0] == 0; /* build.go:229, :232 */
-    if (!skip) {
-        char mode[11], hex[129], line[64];
-        const char *name = rel + 1; /* build.go:250 */
-        if (!plain_safe_name(name)) { w->err = ORACLE_EUNSAFE; return; }
-        if (oracle_mode_string(st.st_mode, mode) != 0) { w->err = ORACLE_EMODE; return; }
-        sb_puts(w->out, "- name: "); sb_puts(w->out, name); sb_puts(w->out, "\n");
-        if (S_ISREG(st.st_mode)) { /* build.go:240-247 */
-            int e = oracle_sha512sum(path, hex);
-            if (e) { w->err = ORACLE_EIO; w->saved_errno = e; return; }
-            snprintf(line, sizeof line, "  size: %lld\n", (long long)st.st_size);
-            sb_puts(w->out, line);
-            sb_puts(w->out, "  sha512: "); sb_puts(w->out, hex); sb_puts(w->out, "\n");
-        }
-        sb_puts(w->out, "  mode: "); sb_puts(w->out, mode); sb_puts(w->out, "\n");
-        w->nfiles++;
-    }
+    visit(w, path, &st);
+    if (w->err) return;
     /* returning nil (not SkipDir) for /DEBIAN means Walk still descends; the
      * children carry the same prefix and are skipped one by one. */
     if (!S_ISDIR(st.st_mode)) return;
     DIR *d = opendir(path);
-    if (!d) { w->err = ORACLE_EIO; w->saved_errno = errno; return; }
+    if (!d) {
+        /* filepath.Walk: `names, err := readDirNames(path); if err != nil { return walkFn(path, info, err) }` -- the
+         * callback is called a SECOND time for the directory, and writeHashes' callback never looks at its err
+         * argument (build.go:228): the record is appended again, nil is returned, the walk goes on. */
+        visit(w, path, &st);
+        return;
+    }
     char **names = 0; size_t n = 0, cap = 0;
     struct dirent *de;
     while ((de = readdir(d))) {
@@ -302,6 +465,32 @@ static void walk(walkst *w, const char *path)
         free(child); free(names[i]);
     }
     free(names);
+}
+
+/* the callback of writeHashes (snappy/build.go:228-259) */
+static void visit(walkst *w, const char *path, const struct stat *stp)
+{
+    const struct stat st = *stp;
+    const char *rel = path + w->rootlen;
+    int skip = (strncmp(rel, "/DEBIAN", 7) == 0) || rel[0] == 0; /* build.go:229, :232 */
+    if (!skip) {
+        char mode[11], hex[129], line[64];
+        const char *name = rel + 1; /* build.go:250 */
+        if (oracle_mode_string(st.st_mode, mode) != 0) { w->err = ORACLE_EMODE; return; }
+        size_t mark = w->out->n;
+        sb_puts(w->out, "- name:");
+        if (name_scalar(w->out, name) != 0) { w->out->n = mark; w->err = ORACLE_EUNSAFE; return; }
+        sb_puts(w->out, "\n");
+        if (S_ISREG(st.st_mode)) { /* build.go:240-247 */
+            int e = oracle_sha512sum(path, hex);
+            if (e) { w->err = ORACLE_EIO; w->saved_errno = e; return; }
+            snprintf(line, sizeof line, "  size: %lld\n", (long long)st.st_size);
+            sb_puts(w->out, line);
+            sb_puts(w->out, "  sha512: "); sb_puts(w->out, hex); sb_puts(w->out, "\n");
+        }
+        sb_puts(w->out, "  mode: "); sb_puts(w->out, mode); sb_puts(w->out, "\n");
+        w->nfiles++;
+    }
 }
 
 /* writeHashes minus the file write: YAML text in *yaml_out (free with

@@ -29,8 +29,9 @@ EXPORTS = [
     "snaphash_get_stats_ex", "snaphash_get_device_stats", "snaphash_tree_ex",
     "snaphash_batch_begin", "snaphash_batch_append", "snaphash_batch_end", "snaphash_batch_finish", "snaphash_batch_abort",
     "snaphash_tar_create", "snaphash_tar_create_fn", "snaphash_gzip_buffer", "snaphash_get_targz_stats",
+    "snaphash_get_engine_info", "snaphash_numa_probe",
 ]
-FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER = 1, 2, 4
+FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER, FLAG_GPU_ONLY, FLAG_NO_NUMA = 1, 2, 4, 8, 16
 
 
 class Config(ctypes.Structure):
@@ -44,8 +45,14 @@ class Config(ctypes.Structure):
 class StatsEx(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("n_devices", ctypes.c_uint32), ("gather_kind", ctypes.c_uint32),
                 ("gather_checked", ctypes.c_uint32), ("gather_ms", ctypes.c_double), ("gpu_bytes", ctypes.c_uint64),
-                ("host_bytes", ctypes.c_uint64), ("host_streams", ctypes.c_uint64), ("handover_streams", ctypes.c_uint64),
+                ("host_bytes", ctypes.c_uint64), ("host_streams", ctypes.c_uint64), ("reserved3", ctypes.c_uint64),
                 ("host_ms", ctypes.c_double)]
+
+
+class EngineInfo(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("numa_node", ctypes.c_int32),
+                ("staging_node", ctypes.c_int32), ("fill_threads", ctypes.c_uint32), ("n_cpus", ctypes.c_uint32),
+                ("pci_bus_id", ctypes.c_char * 32)]
 
 
 class Stats(ctypes.Structure):
@@ -147,6 +154,8 @@ def lib():
     L.snaphash_gzip_buffer.argtypes = [vp, vp, sz, ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.snaphash_get_targz_stats.argtypes = [vp, ctypes.POINTER(TargzStats)]
     L.snaphash_get_targz_stats.restype = None
+    L.snaphash_get_engine_info.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(EngineInfo)]
+    L.snaphash_numa_probe.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), vp, sz, ctypes.POINTER(sz)]
     _lib = L
     return L
 
@@ -161,9 +170,17 @@ def strerror(code):
 class Context:
     """One snaphash_ctx: one GPU (device=) or several (devices=[...], [-1] = all visible; the file list of a
     call is then LPT-sharded inside the library and the digests gathered over RCCL), one call in flight.
-    host_threads > 0 opts into hybrid scheduling (oversize streams finish on host threads)."""
+    host_threads: 0 = the library's default (a stream that would set the makespan of its batch all by itself -- the
+    archive next to its tree -- is hashed on a host thread), N > 0 = N threads and the full planner;
+    flags=FLAG_GPU_ONLY keeps every byte on the GPU (kernel parity tests, roofline runs)."""
 
-    def __init__(self, device=-1, staging_bytes=0, kernel=KERNEL_AUTO, stream=None, devices=None, host_threads=0, flags=0):
+    # flags a Context gets when the caller names none: 0 = the library's defaults.  The -m gpu suite sets it to
+    # FLAG_GPU_ONLY (tests/conftest.py) so that every test exercises the HIP kernels unless it asks for the default.
+    DEFAULT_FLAGS = 0
+
+    def __init__(self, device=-1, staging_bytes=0, kernel=KERNEL_AUTO, stream=None, devices=None, host_threads=0, flags=None):
+        if flags is None:
+            flags = Context.DEFAULT_FLAGS
         cfg = Config(ctypes.sizeof(Config), device, staging_bytes, kernel, 0, stream)
         if devices is not None:
             self._devs = (ctypes.c_int32 * len(devices))(*devices)
@@ -355,6 +372,13 @@ class Context:
         self._check(lib().snaphash_get_stats_ex(self._h, ctypes.byref(s)))
         return {f[0]: getattr(s, f[0]) for f in StatsEx._fields_}
 
+    def engine_info(self, i):
+        e = EngineInfo(ctypes.sizeof(EngineInfo))
+        self._check(lib().snaphash_get_engine_info(self._h, i, ctypes.byref(e)))
+        out = {f[0]: getattr(e, f[0]) for f in EngineInfo._fields_}
+        out["pci_bus_id"] = e.pci_bus_id.decode()
+        return out
+
     def device_stats(self, i):
         s, d = Stats(), ctypes.c_int32()
         self._check(lib().snaphash_get_device_stats(self._h, i, ctypes.byref(d), ctypes.byref(s)))
@@ -453,6 +477,16 @@ def parse_yaml(text):
         return arch.value.decode(), out
     finally:
         lib().snaphash_records_free(h)
+
+
+def numa_probe(sysfs_root, pci_bus_id):
+    """The engines' topology probe on any sysfs tree -> (node, [cpus])."""
+    node, n = ctypes.c_int32(), ctypes.c_size_t()
+    cpus = (ctypes.c_int32 * 4096)()
+    rc = lib().snaphash_numa_probe(os.fsencode(sysfs_root), pci_bus_id.encode(), ctypes.byref(node), cpus, 4096, ctypes.byref(n))
+    if rc:
+        raise SnaphashError(rc)
+    return node.value, list(cpus[:min(n.value, 4096)])
 
 
 def mode_string(st_mode):

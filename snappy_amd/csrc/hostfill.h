@@ -1,0 +1,75 @@
+// hostfill.h -- the host side of an engine's staging: where its pinned memory lives and which threads fill it.
+// Internal.  No reference counterpart: helpers.Sha512sum (helpers/helpers.go:187-201) reads through a 32 KiB
+// io.Copy buffer on the calling goroutine; here the bytes of a whole batch are moved into pinned memory by a pool
+// of threads that sits on the GPU's own NUMA node, because with one engine per GPU eight engines
+// move 8 x 55 GB/s and a staging buffer on the far socket would put every byte on the inter-socket link twice.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace snaphash {
+
+// ---- NUMA topology from sysfs (root = "/sys"; the tests hand in a fake tree) ----------------------------------
+// NUMA node of the PCI function `bdf` ("0000:c1:00.0", as hipDeviceGetPCIBusId spells it), -1 when sysfs does not say
+// (single-node boxes report -1).
+int numa_node_of_pci(const std::string& sysfs_root, const std::string& bdf);
+// CPUs of a node (<root>/devices/system/node/node<N>/cpulist, "0-15,128-143"); empty when unknown.
+std::vector<int> numa_cpus_of_node(const std::string& sysfs_root, int node);
+std::vector<int> parse_cpulist(const std::string& text);
+int numa_node_count(const std::string& sysfs_root);
+
+// Memory policy of the calling thread: prefer `node` for the allocations that follow (set_mempolicy MPOL_PREFERRED;
+// no libnuma: the raw system call), and back to the default.  false when the kernel refuses (no NUMA, seccomp).
+bool numa_prefer_node(int node);
+void numa_default_policy();
+// Node the page holding `addr` lives on (get_mempolicy MPOL_F_NODE | MPOL_F_ADDR), -1 when unknown.
+int numa_node_of_address(const void* addr);
+// CPUs the process may run on (sched_getaffinity): a 1-GPU slice of a big host sees its share, not the machine.
+unsigned usable_cpus();
+
+// ---- a persistent pool of fill threads, pinned to a CPU set ---------------------------------------------------
+// parallel_for(n, T, fn): fn(i) for i in [0, n) on at most T of the pool's threads plus the caller; returns when
+// all are done.  One call at a time (an engine has one batch being filled at any moment).
+class FillPool {
+public:
+    FillPool() = default;
+    ~FillPool();
+    FillPool(const FillPool&) = delete;
+    FillPool& operator=(const FillPool&) = delete;
+    // (re)sizes the pool; threads are created lazily by parallel_for.  cpus empty = no affinity.
+    void configure(unsigned max_threads, const std::vector<int>& cpus);
+    void parallel_for(size_t n, unsigned threads, const std::function<void(size_t)>& fn);
+    unsigned max_threads() const { return max_threads_; }
+    const std::vector<int>& cpus() const { return cpus_; }
+
+private:
+    void worker(unsigned id);
+    void stop();
+    unsigned max_threads_ = 0;
+    std::vector<int> cpus_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    uint64_t epoch_ = 0;       // bumped per parallel_for
+    unsigned want_ = 0;        // pool threads asked to join the current job
+    unsigned running_ = 0;     // pool threads still inside the current job
+    bool quit_ = false;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0;
+    std::atomic<size_t>* next_ = nullptr;
+};
+
+// memcpy into a staging buffer that the CPU will not read again: non-temporal stores for large pieces (no
+// read-for-ownership of the destination lines: a quarter less host memory traffic per staged byte), plain memcpy
+// for small ones.
+void copy_to_staging(void* dst, const void* src, size_t n);
+
+} // namespace snaphash

@@ -97,14 +97,12 @@ int walk_tree(const char* build_dir, std::vector<Record>& out, int* err_no)
 
 // ---- yaml.v2 emitter for hashesYaml ---------------------------------------------
 
-// The only scalar style the reference pins is the plain one
-// (hashes_test.go:89-103).  yaml.v2 quotes or tags scalars that would resolve to
-// another type or that libyaml's analyzer rejects as plain; those rules are not
-// pinned by any reference test, so names outside this conservative set are
-// refused (SNAPHASH_ENAME) rather than guessed at.
+// The only scalar style the reference pins is the plain one (hashes_test.go:89-103): names inside this
+// conservative set are written as they are.  Every other name goes through yamlscalar.cpp, the restatement of
+// yaml.v2's style selection and scalar writers (unpinned by the reference's tests; see that file).
 bool plain_safe_name(const std::string& s)
 {
-    if (s.empty() || s.size() > 1000) return false;
+    if (s.empty() || s.size() > 72) return false; // 8 + 72 = column 80: no folding can be due either
     bool alpha = false;
     for (unsigned char c : s) {
         const bool ok = (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_' ||
@@ -147,11 +145,13 @@ int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64],
     size_t fi = 0;
     char num[32];
     for (const Record& r : recs) {
-        if (!plain_safe_name(r.name)) return SNAPHASH_ENAME;
         char mode[11];
         int rc = mode_string(r.st_mode, mode);
         if (rc) return rc;
-        out += "- name: "; out += r.name; out += '\n';
+        out += "- name:";
+        if (plain_safe_name(r.name)) { out += ' '; out += r.name; } // the pinned case (hashes_test.go:89-103), short cut
+        else if ((rc = yaml_append_name_scalar(r.name, 7, 4, out)) != SNAPHASH_OK) return rc;
+        out += '\n';
         if (r.is_regular) { // size (*int64, omitempty on nil only: "size: 0" IS emitted), then sha512
             snprintf(num, sizeof num, "%lld", (long long)r.size);
             out += "  size: "; out += num; out += '\n';
@@ -210,6 +210,10 @@ bool parse_scalar(const std::string& v, std::string& out)
             case '"': out += '"'; break;
             case '/': out += '/'; break;
             case '\\': out += '\\'; break;
+            case 'N': out += "\xC2\x85"; break;     // NEL
+            case '_': out += "\xC2\xA0"; break;     // NBSP
+            case 'L': out += "\xE2\x80\xA8"; break; // LS
+            case 'P': out += "\xE2\x80\xA9"; break; // PS
             case 'x': case 'u': case 'U': {
                 const int nd = v[i] == 'x' ? 2 : (v[i] == 'u' ? 4 : 8);
                 if (i + nd >= v.size()) return false;
@@ -281,11 +285,31 @@ int parse_yaml(const char* text, size_t len, ParsedHashes& out)
     bool in_files = false;
     int skip_indent = -1; // inside a nested block we ignore (xattr)
     ParsedRecord* cur = nullptr;
-    for (const std::string& raw : lines) {
-        std::string line = raw;
+    auto indent_of = [](const std::string& l) { size_t k = 0; while (k < l.size() && l[k] == ' ') ++k; return k; };
+    for (size_t li = 0; li < lines.size(); ++li) {
+        std::string line = lines[li];
         while (!line.empty() && (line.back() == '\r')) line.pop_back();
         size_t ind = 0;
         while (ind < line.size() && line[ind] == ' ') ++ind;
+        // A scalar the emitter folded (yaml.v2 breaks lines past column 80 at a space, yamlscalar.cpp): the lines that
+        // follow a "key: value" of a list item and are indented deeper than the item's keys continue the value; the
+        // break and the indentation stand for one space.
+        if (in_files && skip_indent < 0 && ind < line.size() && line[ind] != '#') {
+            const size_t key_col = line[ind] == '-' ? ind + 2 : ind;
+            const size_t colon = line.find(": ", ind);
+            if (colon != std::string::npos && colon + 2 < line.size()) {
+                while (li + 1 < lines.size()) {
+                    std::string nx = lines[li + 1];
+                    while (!nx.empty() && (nx.back() == '\r' || nx.back() == ' ')) nx.pop_back();
+                    const size_t ni = indent_of(nx);
+                    if (nx.empty() || ni <= key_col) break;
+                    while (!line.empty() && line.back() == ' ') line.pop_back();
+                    line += ' ';
+                    line.append(nx, ni, std::string::npos);
+                    ++li;
+                }
+            }
+        }
         if (ind == line.size() || line[ind] == '#') continue;
         if (line == "---" || line == "...") continue;
         if (skip_indent >= 0) {

@@ -24,6 +24,7 @@ hipError_t launch_wide(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uin
 hipError_t launch_pair(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
 hipError_t launch_split(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
 hipError_t launch_quad(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
+bool have_quad_kernel(); // built with `make QUAD=1` only
 // Byte-range comparison (helpers.FilesAreEqual, reference helpers/cmp.go:31-86, batched): one
 // chunk = up to kCmpChunk bytes of one pair; equal[pair] is cleared when any chunk differs.
 constexpr uint32_t kCmpChunk = 256u << 10;

@@ -23,7 +23,9 @@
 #include <stdint.h>
 
 #include "pair_rounds.inc"
+#if defined(SNAPHASH_WITH_QUAD) // the measured-negative four-lane variant: `make QUAD=1`
 #include "quad_rounds.inc"
+#endif
 #include "sha512_core.h"
 #include "sha512_kernels.h"
 
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(PAIR ? 256 : 192) void sha512_split_kernel(const Jo
     split_helper_wave(sh, wave - kRoundWaves, lane, jb, nblk, steps);
 }
 
+#if defined(SNAPHASH_WITH_QUAD)
 // ---------------------------------------------------------------------------
 // QUAD kernel: as PAIR, with every stream on FOUR lanes of a round wave -- role (e-chain / a-chain) x
 // half (low / high 32 bits) -- so that rotations and bitwise functions are one instruction instead of
@@ -549,6 +552,8 @@ __global__ __launch_bounds__(384) void sha512_quad_kernel(const Job* __restrict_
     }
     split_helper_wave(sh, wave - kRoundWaves, lane, jb, nblk, steps);
 }
+
+#endif // SNAPHASH_WITH_QUAD
 
 // ---------------------------------------------------------------------------
 // Synthetic content generator: file bytes = little-endian
@@ -667,12 +672,26 @@ hipError_t launch_pair(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uin
     return hipGetLastError();
 }
 
+bool have_quad_kernel()
+{
+#if defined(SNAPHASH_WITH_QUAD)
+    return true;
+#else
+    return false;
+#endif
+}
+
 hipError_t launch_quad(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s)
 {
+#if defined(SNAPHASH_WITH_QUAD)
     if (njobs == 0) return hipSuccess;
     const uint32_t grid = (njobs + 63u) / 64u;
     hipLaunchKernelGGL(sha512_quad_kernel, dim3(grid), dim3(384), 0, s, d_jobs, njobs, d_state, d_digests);
     return hipGetLastError();
+#else
+    (void)d_jobs; (void)njobs; (void)d_state; (void)d_digests; (void)s;
+    return hipErrorNotSupported; // snaphash_init refuses SNAPHASH_KERNEL_QUAD in a build without it
+#endif
 }
 
 hipError_t launch_fill_synthetic(uint8_t* d_base, const uint64_t* d_offsets, const uint64_t* d_lens,

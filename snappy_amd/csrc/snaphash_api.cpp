@@ -33,6 +33,7 @@
 #include <mutex>
 
 #include "deflate_kernels.h"
+#include "hostfill.h"
 #include "hostpass.h"
 #include "hostsha.h"
 #include "sha512_core.h"
@@ -113,6 +114,13 @@ struct DevCtx {
     size_t ev_used = 0;
     bool pending = false;
 
+    // host side of the staging (hostfill.h): the GPU's NUMA node, the pool of fill threads that lives there
+    std::string pci_bus_id;
+    int numa_node = -1;        // -1: unknown or not applied (single-node host, SNAPHASH_FLAG_NO_NUMA)
+    int staging_node = -1;     // node the first staging page was found on after allocation (diagnostic)
+    unsigned fill_cap = 12;    // most fill threads this engine uses (the ctx divides the usable CPUs among its engines)
+    FillPool pool;
+
     snaphash_stats stats{};
     double t_call0 = 0;
     std::string last_error;
@@ -139,7 +147,8 @@ struct snaphash_batch;
 
 struct snaphash_ctx {
     std::vector<std::unique_ptr<DevCtx>> dev;
-    uint32_t host_threads = 0;
+    uint32_t host_threads = 0; // threads of the hybrid scheduler (0: every byte on the GPU)
+    bool host_auto = true;     // the default: only streams that set the makespan all by themselves move
     double host_rate = 0.40e9; // bytes/s of one host thread's SHA-512, measured at init when host_threads > 0
     uint32_t flags = 0;
     Rccl rccl;
@@ -233,10 +242,27 @@ int ensure_jobs(DevCtx* c, Job** h, Job** d, size_t* cap, size_t n)
     return SNAPHASH_OK;
 }
 
+// Pinned host memory for an engine: on the GPU's NUMA node when it is known (the calling thread's memory policy
+// prefers that node for the duration of the allocation and hipHostMallocNumaUser tells the runtime to honour it),
+// wherever the runtime puts it otherwise.
+hipError_t host_alloc(DevCtx* c, void** p, size_t bytes)
+{
+    if (c->numa_node >= 0 && numa_prefer_node(c->numa_node)) {
+        const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocNumaUser);
+        numa_default_policy();
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+    }
+    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
 int ensure_slots(DevCtx* c)
 {
     for (Slot& s : c->slot) {
-        if (!s.h_buf) HIP_TRY(c, hipHostMalloc((void**)&s.h_buf, c->staging, hipHostMallocDefault));
+        if (!s.h_buf) {
+            HIP_TRY(c, host_alloc(c, (void**)&s.h_buf, c->staging));
+            if (c->staging_node < 0) { s.h_buf[0] = 0; c->staging_node = numa_node_of_address(s.h_buf); }
+        }
         if (!s.d_buf) HIP_TRY(c, hipMalloc((void**)&s.d_buf, c->staging + 256)); // slack: the deflate kernel peeks 3 bytes past a chunk
         if (!s.done) HIP_TRY(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         if (!s.copied) HIP_TRY(c, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
@@ -355,58 +381,57 @@ struct Source {
 
 struct ReadOp { uint32_t src; uint64_t off; uint64_t n; uint8_t* dst; bool to_eof; };
 
-void run_reads(const std::vector<Source>& src, const std::vector<ReadOp>& ops, std::atomic<int>& first_err,
+// One read operation of a staging fill: file source -> open + pread (io.Copy's semantics: a file that shrank or
+// grew since its size was taken is an error), memory source -> a streaming copy.  Returns 0 or an errno.
+int do_read_op(const Source& s, const ReadOp& op)
+{
+    if (s.mem) { copy_to_staging(op.dst, s.mem + op.off, op.n); return 0; }
+    int err = 0;
+    int fd = open(s.path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) err = errno;
+    uint64_t got = 0;
+    while (!err && got < op.n) {
+        ssize_t r = pread(fd, op.dst + got, op.n - got, (off_t)(op.off + got));
+        if (r < 0) { if (errno == EINTR) continue; err = errno; }
+        else if (r == 0) err = EIO; // file shrank underneath us
+        else got += (uint64_t)r;
+    }
+    if (!err && op.to_eof) { // io.Copy reads to EOF: a file that grew since its size was taken is an error too
+        uint8_t probe;
+        ssize_t r;
+        do r = pread(fd, &probe, 1, (off_t)(op.off + op.n)); while (r < 0 && errno == EINTR);
+        if (r > 0) err = EIO;
+        else if (r < 0) err = errno;
+    }
+    if (fd >= 0) close(fd);
+    return err;
+}
+
+// Fills a staging slot: the engine's pool of fill threads (on the GPU's NUMA node, hostfill.h) runs the operations.
+void run_reads(DevCtx* c, const std::vector<Source>& src, const std::vector<ReadOp>& ops, std::atomic<int>& first_err,
                std::atomic<int64_t>& first_err_src)
 {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    // Staging-fill threads, measured on the GPU box (tools/copy_threads_sweep.sh): memcpy from caller memory
-    // peaks at 6 threads (44 GiB/s end to end; 16 threads: 33 -- they fight the concurrent H2D DMA for host
-    // memory bandwidth), pread of files at 12 (30 GiB/s).  SNAPHASH_COPY_THREADS overrides (1..256).
+    // Staging-fill threads, measured on the GPU box (tools/copy_threads_sweep.sh): copies from caller memory
+    // peak at 6 threads (44 GiB/s end to end; 16 threads: 33 -- they fight the concurrent H2D DMA for host
+    // memory bandwidth), pread of files at 12 (30 GiB/s).  SNAPHASH_COPY_THREADS overrides (1..256); a ctx with
+    // several engines divides the CPUs it may use among them (fill_cap).
     static const int forced = [] {
         const char* e = getenv("SNAPHASH_COPY_THREADS");
         const int v = e ? atoi(e) : 0;
         return (v >= 1 && v <= 256) ? v : 0;
     }();
     const bool from_memory = !ops.empty() && src[ops[0].src].mem != nullptr;
-    const unsigned cap = forced ? (unsigned)forced : (from_memory ? 6u : 12u);
-    const unsigned T = (unsigned)std::min<size_t>(std::min(cap, hw), std::max<size_t>(1, ops.size() / 4));
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= ops.size() || first_err.load()) return;
-            const ReadOp& op = ops[i];
-            const Source& s = src[op.src];
-            if (s.mem) { memcpy(op.dst, s.mem + op.off, op.n); continue; }
-            int err = 0;
-            int fd = open(s.path, O_RDONLY | O_CLOEXEC);
-            if (fd < 0) err = errno;
-            uint64_t got = 0;
-            while (!err && got < op.n) {
-                ssize_t r = pread(fd, op.dst + got, op.n - got, (off_t)(op.off + got));
-                if (r < 0) { if (errno == EINTR) continue; err = errno; }
-                else if (r == 0) err = EIO; // file shrank underneath us
-                else got += (uint64_t)r;
-            }
-            if (!err && op.to_eof) { // io.Copy reads to EOF: a file that grew since its size was taken is an error too
-                uint8_t probe;
-                ssize_t r;
-                do r = pread(fd, &probe, 1, (off_t)(op.off + op.n)); while (r < 0 && errno == EINTR);
-                if (r > 0) err = EIO;
-                else if (r < 0) err = errno;
-            }
-            if (fd >= 0) close(fd);
-            if (err) {
-                int z = 0;
-                if (first_err.compare_exchange_strong(z, err)) first_err_src.store(op.src);
-                return;
-            }
+    const unsigned cap = forced ? (unsigned)forced : std::min(c->fill_cap, from_memory ? 6u : 12u);
+    const unsigned T = (unsigned)std::min<size_t>(cap, std::max<size_t>(1, ops.size() / 4));
+    c->pool.parallel_for(ops.size(), T, [&](size_t i) {
+        if (first_err.load(std::memory_order_relaxed)) return;
+        const ReadOp& op = ops[i];
+        const int err = do_read_op(src[op.src], op);
+        if (err) {
+            int z = 0;
+            if (first_err.compare_exchange_strong(z, err)) first_err_src.store(op.src);
         }
-    };
-    if (T <= 1) { worker(); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; ++t) th.emplace_back(worker);
-    for (auto& t : th) t.join();
+    });
 }
 
 // Hashes src[i].gpu_len bytes of every source on this engine's device.  digests (host, n*64, may be NULL):
@@ -489,7 +514,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         const double tb2 = now_ms();
         t_plan += tb2 - tb1;
 
-        run_reads(src, ops, first_err, first_err_src);
+        run_reads(c, src, ops, first_err, first_err_src);
         if (first_err.load()) break;
         const double tb3 = now_ms();
         t_read += tb3 - tb2;
@@ -656,6 +681,7 @@ int gather_digest_slabs(snaphash_ctx* x, const std::vector<size_t>& cnt, size_t 
 // advances a lone stream at kGpuStreamRate whatever surrounds it, a host core at kHostRate.
 constexpr double kGpuStreamRate = 44e6;
 constexpr double kGpuAggregate = 40e9; // PCIe-inclusive rate of one device's staging engine
+constexpr uint64_t kAutoHostMinBytes = 4u << 20; // default configuration: a stream shorter than this (< 0.1 s of GPU time) never moves
 
 // bytes per second of the library's host SHA-512 on one core of THIS box (hosts differ 3x): timed once,
 // on a 2 MiB buffer, when a ctx with host_threads > 0 is created
@@ -678,7 +704,12 @@ double measure_host_rate()
 
 // Streams sorted longest first; moves the longest to the host pool while that shortens the modelled
 // makespan max(GPU, host).  Returns per-stream 1 = host.
-std::vector<uint8_t> plan_host_streams(const std::vector<Source>& src, unsigned threads, size_t ndev, double host_rate)
+// only_makespan_setters (the default configuration): a stream is a candidate only while it is at least
+// kAutoHostMinBytes long and its own single-stream GPU time exceeds the modelled GPU time of everything behind it
+// -- the archive next to its tree, a 1 GiB member -- so a batch of many similar streams (config 2) and every small
+// batch stay on the GPU whole.
+std::vector<uint8_t> plan_host_streams(const std::vector<Source>& src, unsigned threads, size_t ndev, double host_rate,
+                                       bool only_makespan_setters)
 {
     const size_t n = src.size();
     std::vector<uint8_t> on_host(n, 0);
@@ -699,6 +730,10 @@ std::vector<uint8_t> plan_host_streams(const std::vector<Source>& src, unsigned 
     double host_makespan = 0, best = gpu_time(0);
     size_t best_k = 0;
     for (size_t k = 0; k < n; ++k) {
+        if (only_makespan_setters &&
+            (src[order[k]].len < kAutoHostMinBytes ||
+             (double)src[order[k]].len / kGpuStreamRate <= suffix[k + 1] / (kGpuAggregate * (double)ndev)))
+            break;
         const double t = pool.top() + (double)src[order[k]].len / host_rate;
         pool.pop();
         pool.push(t);
@@ -752,7 +787,7 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     if (n == 0) return SNAPHASH_OK;
     const size_t nd = x->dev.size();
     for (Source& s : src) s.gpu_len = s.len;
-    const std::vector<uint8_t> on_host = plan_host_streams(src, x->host_threads, nd, x->host_rate);
+    const std::vector<uint8_t> on_host = plan_host_streams(src, x->host_threads, nd, x->host_rate, x->host_auto);
 
     // GPU part: LPT over the devices by SHA-512 block count (deterministic)
     std::vector<uint32_t> gidx;
@@ -1040,10 +1075,28 @@ try {
     if (devs.size() > 64) return init_fail(SNAPHASH_EINVAL, "more than 64 engines");
     std::unique_ptr<snaphash_ctx> x(new (std::nothrow) snaphash_ctx());
     if (!x) return SNAPHASH_ENOMEM;
-    if (v2) { x->host_threads = std::min<uint32_t>(cfg->host_threads, 256); x->flags = cfg->flags; }
-    if (!cfg && getenv("SNAPHASH_HOST_THREADS")) // likewise: hybrid scheduling for a ctx created without a config
+    // Hybrid scheduling (snaphash.h, snaphash_config.host_threads): automatic by default -- only streams that would
+    // set the makespan of their batch all by themselves move to a host thread; an explicit count turns the full planner
+    // on; SNAPHASH_FLAG_GPU_ONLY keeps every byte on the GPU.
+    const unsigned ncpu = usable_cpus();
+    x->host_threads = std::min(12u, ncpu);
+    x->host_auto = true;
+    if (v2) {
+        x->flags = cfg->flags;
+        if (cfg->host_threads) { x->host_threads = std::min<uint32_t>(cfg->host_threads, 256); x->host_auto = false; }
+    }
+    if (!cfg && getenv("SNAPHASH_HOST_THREADS")) { // likewise for a ctx created without a config: N threads, 0 = none
         x->host_threads = (uint32_t)std::min<unsigned long>(strtoul(getenv("SNAPHASH_HOST_THREADS"), nullptr, 10), 256);
+        x->host_auto = false;
+    }
+    if (x->flags & SNAPHASH_FLAG_GPU_ONLY) x->host_threads = 0;
     if (x->host_threads) x->host_rate = measure_host_rate();
+    // where the staging memory and its fill threads live: the GPU's own NUMA node (hostfill.h).  SNAPHASH_SYSFS_ROOT
+    // points the topology probe at another tree (the tests' fake one).
+    const char* sysfs_env = getenv("SNAPHASH_SYSFS_ROOT");
+    const std::string sysfs = sysfs_env && *sysfs_env ? sysfs_env : "/sys";
+    const bool numa_on = !(x->flags & SNAPHASH_FLAG_NO_NUMA) && numa_node_count(sysfs) > 1;
+    const unsigned fill_cap = std::max(2u, std::min(12u, ncpu / (unsigned)devs.size()));
     for (size_t k = 0; k < devs.size(); ++k) {
         const int dev = devs[k];
         if (dev < 0 || dev >= ndev) {
@@ -1067,9 +1120,26 @@ try {
             if (v1) {
                 if (cfg->staging_bytes) c->staging = (cfg->staging_bytes + kAlign - 1) & ~(uint64_t)(kAlign - 1);
                 c->kernel_pref = cfg->kernel;
+                if (c->kernel_pref == SNAPHASH_KERNEL_QUAD && !have_quad_kernel()) {
+                    rc = SNAPHASH_EINVAL;
+                    e = hipSuccess;
+                    why = "SNAPHASH_KERNEL_QUAD is not in this build (make QUAD=1)";
+                }
                 if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
             }
+        }
+        if (!rc) {
             if (c->staging < (1u << 16)) c->staging = 1u << 16;
+            c->fill_cap = fill_cap;
+            std::vector<int> cpus;
+            char bdf[64] = {0};
+            if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, dev) == hipSuccess) c->pci_bus_id = bdf;
+            else (void)hipGetLastError();
+            if (numa_on) {
+                c->numa_node = numa_node_of_pci(sysfs, c->pci_bus_id);
+                cpus = numa_cpus_of_node(sysfs, c->numa_node);
+            }
+            c->pool.configure(256, cpus); // threads are created as batches ask for them (run_reads caps the count)
             if (!c->stream) {
                 if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { rc = SNAPHASH_EDEVICE; why = "hipStreamCreateWithFlags"; }
                 else c->own_stream = true;
@@ -1204,7 +1274,7 @@ static int tree_impl(snaphash_ctx* x, const char* build_dir, const char* data_ta
     const double tw1 = now_ms();
     if (rc) return fail(x, rc, rc == SNAPHASH_EIO ? std::string(build_dir) + ": " + strerror(en) : "Unknown file mode");
     for (const Record& r : recs)
-        if (!plain_safe_name(r.name)) return fail(x, SNAPHASH_ENAME, "name needs YAML quoting: " + r.name);
+        if (!name_emittable(r.name)) return fail(x, SNAPHASH_ENAME, "name outside what the YAML emitter restates (yamlscalar.cpp): " + r.name);
     std::vector<const char*> paths;
     std::vector<int64_t> sizes;
     if (data_tar) { paths.push_back(data_tar); sizes.push_back(-1); } // element 0 = the archive, as in the Go batch shape
@@ -1480,7 +1550,6 @@ int snaphash_batch_begin(snaphash_ctx* x, size_t n_streams, snaphash_batch** out
 try {
     if (!x || !out) return fail(x, SNAPHASH_EINVAL, "bad argument");
     *out = nullptr;
-    if (x->dev.size() != 1) return fail(x, SNAPHASH_EINVAL, "streaming batches need a single-device ctx");
     if (n_streams > 0xffffffffull) return fail(x, SNAPHASH_EINVAL, "too many streams");
     TOP_ENTER(x);
     DevCtx* c = x->d0();
@@ -1732,26 +1801,13 @@ int files_equal_impl(DevCtx* c, const char* const* a, const char* const* b, size
             ++t;
         }
         h.ok.assign(h.segs.size(), 1);
-        {
-            std::atomic<size_t> next{0};
-            auto worker = [&]() {
-                for (;;) {
-                    const size_t i = next.fetch_add(1);
-                    if (i >= h.segs.size()) return;
-                    const Seg& g = h.segs[i];
-                    const CmpPair& p = todo[g.t];
-                    if (!read_exact(a[p.idx], g.off, g.n, c->slot[0].h_buf + g.at) ||
-                        !read_exact(b[p.idx], g.off, g.n, c->slot[1].h_buf + g.at))
-                        h.ok[i] = 0;
-                }
-            };
-            const unsigned T = (unsigned)std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
-                                                          std::max<size_t>(1, h.segs.size() / 2));
-            std::vector<std::thread> th;
-            for (unsigned k = 1; k < T; ++k) th.emplace_back(worker);
-            worker();
-            for (auto& x : th) x.join();
-        }
+        c->pool.parallel_for(h.segs.size(), (unsigned)std::min<size_t>(c->fill_cap, std::max<size_t>(1, h.segs.size() / 2)), [&](size_t i) {
+            const Seg& g = h.segs[i];
+            const CmpPair& p = todo[g.t];
+            if (!read_exact(a[p.idx], g.off, g.n, c->slot[0].h_buf + g.at) ||
+                !read_exact(b[p.idx], g.off, g.n, c->slot[1].h_buf + g.at))
+                h.ok[i] = 0;
+        });
         if (h.segs.size() > h.cap) {
             if (h.h_res) (void)hipHostFree(h.h_res);
             if (h.d_eq) (void)hipFree(h.d_eq);
@@ -1814,9 +1870,40 @@ int snaphash_files_equal(snaphash_ctx* x, const char* const* a, const char* cons
 try {
     if (!x || (n && (!a || !b || !equal))) return fail(x, SNAPHASH_EINVAL, "bad argument");
     TOP_ENTER(x);
-    DevCtx* c = x->d0(); // the comparison scan runs on the ctx's first engine
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = lift(x, c, files_equal_impl(c, a, b, n, equal));
+    const size_t nd = x->dev.size();
+    int rc = SNAPHASH_OK;
+    if (nd == 1 || n < 2) {
+        DevCtx* c = x->d0();
+        HIP_TRY(c, hipSetDevice(c->device));
+        rc = lift(x, c, files_equal_impl(c, a, b, n, equal));
+    } else {
+        // pairs are independent: LPT by size over the engines, one host thread each, every engine on its own link
+        std::vector<uint64_t> lens(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            struct stat st;
+            if (a[i] && stat(a[i], &st) == 0 && S_ISREG(st.st_mode)) lens[i] = (uint64_t)st.st_size;
+        }
+        std::vector<int32_t> shard(n);
+        lpt_assign(lens.data(), n, (int)nd, shard.data());
+        struct Part { std::vector<const char*> a, b; std::vector<size_t> idx; std::vector<uint8_t> eq; int rc = 0; };
+        std::vector<Part> part(nd);
+        for (size_t i = 0; i < n; ++i) { Part& p = part[shard[i]]; p.a.push_back(a[i]); p.b.push_back(b[i]); p.idx.push_back(i); }
+        auto run = [&](size_t d) {
+            Part& p = part[d];
+            p.eq.assign(p.idx.size(), 0);
+            DevCtx* c = x->dev[d].get();
+            if (hipSetDevice(c->device) != hipSuccess) { p.rc = fail(c, SNAPHASH_EDEVICE, "hipSetDevice"); return; }
+            p.rc = files_equal_impl(c, p.a.data(), p.b.data(), p.idx.size(), p.eq.data());
+        };
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < nd; ++d) th.emplace_back(run, d);
+        run(0);
+        for (auto& t : th) t.join();
+        for (size_t d = 0; d < nd; ++d) {
+            if (part[d].rc && !rc) rc = lift(x, x->dev[d].get(), part[d].rc);
+            for (size_t k = 0; k < part[d].idx.size(); ++k) equal[part[d].idx[k]] = part[d].eq[k];
+        }
+    }
     merge_stats(x);
     end_top(x, t_top0_);
     return rc;
@@ -2036,6 +2123,35 @@ try {
     *out = c->ex;
     out->struct_size = sizeof(snaphash_stats_ex);
     out->n_devices = (uint32_t)c->dev.size();
+    return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
+}
+
+int snaphash_get_engine_info(const snaphash_ctx* c, uint32_t i, snaphash_engine_info* out)
+try {
+    if (!c || !out || i >= c->dev.size() || out->struct_size < sizeof(snaphash_engine_info)) return SNAPHASH_EINVAL;
+    const DevCtx* d = c->dev[i].get();
+    memset(out, 0, sizeof *out);
+    out->struct_size = sizeof *out;
+    out->device = d->device;
+    out->numa_node = d->numa_node;
+    out->staging_node = d->staging_node;
+    out->fill_threads = d->fill_cap;
+    out->n_cpus = (uint32_t)d->pool.cpus().size();
+    snprintf(out->pci_bus_id, sizeof out->pci_bus_id, "%s", d->pci_bus_id.c_str());
+    return SNAPHASH_OK;
+} catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
+}
+
+int snaphash_numa_probe(const char* sysfs_root, const char* pci_bus_id, int32_t* node, int32_t* cpus, size_t cap, size_t* n_cpus)
+try {
+    if (!sysfs_root || !pci_bus_id || !node) return SNAPHASH_EINVAL;
+    *node = numa_node_of_pci(sysfs_root, pci_bus_id);
+    const std::vector<int> v = numa_cpus_of_node(sysfs_root, *node);
+    if (n_cpus) *n_cpus = v.size();
+    for (size_t k = 0; cpus && k < v.size() && k < cap; ++k) cpus[k] = v[k];
     return SNAPHASH_OK;
 } catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
     return SNAPHASH_ENOMEM;

@@ -17,7 +17,19 @@ namespace {
 int64_t walk_names(const std::string& path, std::vector<WalkEntry>& ents, size_t self, int* err_no)
 {
     DIR* d = opendir(path.c_str());
-    if (!d) { *err_no = errno; return (int64_t)self; }
+    if (!d) {
+        // filepath.Walk: `names, err := readDirNames(path); if err != nil { return walkFn(path, info, err) }` -- the
+        // callback runs a SECOND time for the directory, and neither of the reference's callbacks looks at the err
+        // it is handed (snappy/build.go:228 ignores it, clickdeb/deb.go:285-286 shadows it with its own Lstat): the
+        // entry is emitted again and the walk goes on behind it.
+        WalkEntry again;
+        again.path = path;
+        again.st = ents[self].st;
+        again.have_st = ents[self].have_st;
+        ents.push_back(std::move(again));
+        (void)err_no;
+        return -1;
+    }
     std::vector<std::pair<std::string, unsigned char>> names;
     while (struct dirent* de = readdir(d)) {
         if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;

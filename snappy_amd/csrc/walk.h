@@ -18,9 +18,11 @@ struct WalkEntry {
 // Lstat semantics (a symlink to a directory is an entry, not descended).  Two phases: the names are listed serially,
 // descending by the directory entry's type where the filesystem gives one (one opendir per directory instead of one
 // lstat per entry), then every entry is Lstat'ed on a few threads.
-// Returns 0, or -1 when an Lstat or a directory listing failed: then *err_no / *err_path say what, and `ents` holds
-// exactly the entries the serial loop would have visited before the failure (a directory that could not be listed
-// is the last of them: Walk has visited it when ReadDir fails).
+// A directory that cannot be listed is NOT an error, as in the reference: Walk hands the ReadDir error to the callback
+// in a second call for that directory, both callbacks ignore it (snappy/build.go:228, clickdeb/deb.go:285-286), so the
+// directory appears twice and the walk continues.
+// Returns 0, or -1 when an Lstat failed: then *err_no / *err_path say what, and `ents` holds exactly the entries the
+// serial loop would have visited before the failure.
 int walk_entries(const char* root, std::vector<WalkEntry>& ents, int* err_no, std::string* err_path);
 
 } // namespace snaphash

@@ -71,12 +71,34 @@ int main(int argc, char** argv)
             return 9;
         }
     }
+    // The name emitter (yamlscalar.cpp) against the parser: random names out of an alphabet rich in YAML indicators,
+    // spaces (folding), quotes, escapes and multi-byte characters.  Whatever is emitted must parse back to the name.
+    static const char* const piece[] = {"a", "b", " ", "  ", ":", ": ", "#", " #", "'", "\"", "\\", "-", "?", "~", "1", "0x", ".", "e", "_",
+                                        "\t", "\x01", "\xc3\xa9", "\xe2\x82\xac", "\xf0\x9f\x98\x80", "\xef\xbb\xbf", "\xff", "word ", "@", "!", "&",
+                                        "*", "|", ">", "%", "`", "[", "]", "{", "}", ",", "true", "null", "+", "\xc2\xa0", "\x7f"};
+    int emitted = 0, refused = 0;
+    for (int it = 0; it < 20000; ++it) {
+        std::string name;
+        const int np = 1 + rnd() % ((it % 7 == 0) ? 60 : 8);
+        for (int k = 0; k < np; ++k) name += piece[rnd() % (sizeof piece / sizeof *piece)];
+        std::string doc = "archive-sha512: 00\nfiles:\n- name:";
+        const int rc = yaml_append_name_scalar(name, 7, 4, doc);
+        if (rc == SNAPHASH_ENAME) { ++refused; continue; }
+        if (rc != SNAPHASH_OK) return 12;
+        ++emitted;
+        doc += "\n  mode: frw-r--r--\n";
+        ParsedHashes p;
+        if (parse_yaml(doc.data(), doc.size(), p) != SNAPHASH_OK || p.files.size() != 1 || p.files[0].name != name) {
+            fprintf(stderr, "name round trip failed for [%s]\n%s", name.c_str(), doc.c_str());
+            return 13;
+        }
+    }
     uint32_t mode;
     if (mode_parse("", &mode) == SNAPHASH_OK) return 10;
     std::vector<uint64_t> lens(1000);
     std::vector<int32_t> shard(1000);
     for (auto& l : lens) l = rnd() % (1u << 26);
     if (lpt_assign(lens.data(), lens.size(), 8, shard.data()) != SNAPHASH_OK) return 11;
-    printf("asan driver ok: %zu records, %d mutated documents accepted, %d rejected\n", recs.size(), ok, bad);
+    printf("asan driver ok: %zu records, %d mutated documents accepted, %d rejected; %d random names emitted and read back, %d refused\n", recs.size(), ok, bad, emitted, refused);
     return 0;
 }

@@ -105,7 +105,7 @@ def test_fifo_aborts_the_pass(oracle, tmp_path):
 def test_unsafe_name_refused(oracle, tmp_path):
     b = tmp_path / "b"
     b.mkdir()
-    (b / "has space").write_bytes(b"1")
+    (b / "0o17").write_bytes(b"1")  # a string or an integer depending on the Go release: not restated, refused
     tar = tmp_path / "t"
     tar.write_bytes(b"")
     with pytest.raises(oracle.OracleError) as e:

@@ -21,6 +21,7 @@
 // One block is prefetched into registers while the previous one is hashed.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pair_rounds.inc"
 #if defined(SNAPHASH_WITH_QUAD) // the measured-negative four-lane variant: `make QUAD=1`
@@ -76,7 +77,12 @@ __device__ __forceinline__ void store_digest_be(uint8_t* out, const uint64_t H[8
 // chip: every VALU instruction advances 64 streams; saturates the VALUs at
 // ~1.05 TB/s from 65 536 streams on (profiles/r01_regime_sweep.txt).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void sha512_wide_kernel(const Job* __restrict__ jobs, uint32_t njobs,
+#if defined(SNAPHASH_WIDE_WAVES) // experiment: ask the register allocator for that many waves per SIMD
+#define SNAPHASH_WIDE_ATTR __attribute__((amdgpu_waves_per_eu(SNAPHASH_WIDE_WAVES, SNAPHASH_WIDE_WAVES)))
+#else
+#define SNAPHASH_WIDE_ATTR
+#endif
+__global__ __launch_bounds__(64) SNAPHASH_WIDE_ATTR void sha512_wide_kernel(const Job* __restrict__ jobs, uint32_t njobs,
                                                          uint64_t* __restrict__ state,
                                                          uint8_t* __restrict__ digests)
 {
@@ -155,6 +161,65 @@ __global__ __launch_bounds__(64) void sha512_wide_kernel(const Job* __restrict__
         compress_block(H, w, b < nblk, d_K512);
     }
 
+    if (have) {
+        if (fin) {
+            store_digest_be(digests + (uint64_t)jb.idx * 64, H);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) state[(uint64_t)jb.idx * 8 + k] = H[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// WIDE, direct form: as above without the LDS tile.  Every lane fetches ITS OWN 128-byte block with eight
+// global_load_dwordx4 (one cache line per lane, all of it used by the eight loads back to back: the HBM traffic
+// stays 1x, the address unit sees 64 lines per instruction -- ~0.5 k cycles of it per 16 k-cycle block).  No tile,
+// no cooperative pointers, no register prefetch: 56 VGPRs less, no LDS, so 5 waves per SIMD instead of 3 and the
+// other waves hide the load latency.  For the saturated regime (>= ~64 k streams), where occupancy is what the
+// dependent chain of a round needs.
+// ---------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void sha512_wide_direct_kernel(
+    const Job* __restrict__ jobs, uint32_t njobs, uint64_t* __restrict__ state, uint8_t* __restrict__ digests)
+{
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    const bool have = slot < njobs;
+    Job jb;
+    if (have) {
+        jb = jobs[slot];
+    } else {
+        jb.data = 0; jb.nbytes = 0; jb.total_prev = 0; jb.idx = 0; jb.flags = 0;
+    }
+    const uint64_t nbytes = jb.nbytes;
+    const uint32_t nfull = (uint32_t)(nbytes >> 7);
+    const uint32_t rem = (uint32_t)(nbytes & 127);
+    const bool fin = (jb.flags & kJobFinal) != 0;
+    const uint32_t nblk = have ? padded_blocks(nbytes, fin) : 0u;
+    const uint64_t total = jb.total_prev + nbytes;
+    const uint32_t npieces = (uint32_t)((nbytes + 15u) >> 4); // 16-byte pieces the stream holds (the last may be partial: the slack behind a stream is readable)
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(jb.data);
+
+    uint64_t H[8];
+    if (jb.flags & kJobFirst) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) H[k] = IV512[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) H[k] = have ? state[(uint64_t)jb.idx * 8 + k] : 0;
+    }
+    for (uint32_t b = 0; __any(b < nblk); ++b) {
+        uint64_t w[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (b * 8u + (uint32_t)k < npieces) q = load_u4(p + (uint64_t)b * 128u + 16u * k);
+            w[2 * k] = be64(q.x, q.y);
+            w[2 * k + 1] = be64(q.z, q.w);
+        }
+        if (__any(b >= nfull && b < nblk)) apply_padding(w, b >= nfull, b - nfull, rem, total);
+        compress_block(H, w, b < nblk, d_K512);
+    }
     if (have) {
         if (fin) {
             store_digest_be(digests + (uint64_t)jb.idx * 64, H);
@@ -652,7 +717,11 @@ hipError_t launch_wide(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uin
 {
     if (njobs == 0) return hipSuccess;
     const uint32_t grid = (njobs + 63u) / 64u;
-    hipLaunchKernelGGL(sha512_wide_kernel, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
+    static const int form = [] { const char* e = getenv("SNAPHASH_WIDE_FORM"); return e ? atoi(e) : 0; }(); // experiment switch
+    if (form == 1) hipLaunchKernelGGL(sha512_wide_direct_kernel<5>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
+    else if (form == 2) hipLaunchKernelGGL(sha512_wide_direct_kernel<6>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
+    else if (form == 3) hipLaunchKernelGGL(sha512_wide_direct_kernel<8>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
+    else hipLaunchKernelGGL(sha512_wide_kernel, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
     return hipGetLastError();
 }
 

@@ -84,6 +84,32 @@ DF_HD void enc_match(uint32_t len, uint32_t dist, uint32_t& bits, uint32_t& n)
 
 namespace snaphash {
 
+// ---- the parse (round 3: hash chains, one workgroup per chunk) -- shared by the kernel and its CPU model ---------
+// A chunk is one DEFLATE block; inside it every position's candidates come from hash chains over the chunk and the
+// kDfMaxDist bytes in front of it (3-byte hash, 16-bit distance links in a ring), the chain is walked at most
+// kDfDepth links starting at the position's own link, and the parse is greedy with one-byte lazy evaluation.
+constexpr uint32_t kDfChunk = 65536;    // input bytes per chunk (one workgroup, one DEFLATE block)
+constexpr uint32_t kDfSeg = 1920;       // positions indexed / searched / parsed per pipeline step: 30 tiles, two for each of 15 searching waves
+constexpr uint32_t kDfRing = 32768;     // entries of the link ring (>= kDfMaxDist + kDfSeg)
+constexpr uint32_t kDfHashBits = 12;
+constexpr uint32_t kDfMaxDist = 28800;  // farthest match; also the bytes in front of the chunk that are indexed (15 segments)
+constexpr uint32_t kDfMinMatch = 3;
+constexpr uint32_t kDfTooFar = 4096;    // a 3-byte match farther than this costs more than its literals (zlib's TOO_FAR)
+#if !defined(SNAPHASH_DF_DEPTH) // (tuning builds override the two search parameters; the CPU model follows)
+#define SNAPHASH_DF_DEPTH 32
+#define SNAPHASH_DF_GOOD 32
+#endif
+constexpr uint32_t kDfDepth = SNAPHASH_DF_DEPTH; // links walked per position
+constexpr uint32_t kDfGood = SNAPHASH_DF_GOOD;   // a match this long cuts what is left of the walk to a quarter (zlib's good_length idea)
+constexpr uint32_t kDfNice = 128;       // a match this long ends the walk
+static_assert(kDfRing >= kDfMaxDist + kDfSeg, "a segment is indexed whole before it is searched");
+static_assert(kDfMaxDist % kDfSeg == 0 && kDfSeg % 64 == 0 && kDfSeg % 16 == 0, "whole window segments, whole tiles (a chunk's last segment may be short)");
+
+// bytes a chunk of len input bytes takes as stored blocks: LEN is a 16-bit field, so a full 64 KiB chunk is two blocks
+DF_HD uint32_t deflate_stored_size(uint32_t len) { return len + (len > 65535u ? 10u : 5u); }
+
+DF_HD uint32_t df_hash(uint32_t w) { return ((w & 0xffffffu) * 0x9E3779B1u) >> (32u - kDfHashBits); }
+
 constexpr int kNumLL = 286; // literal/length symbols
 constexpr int kNumD = 30;   // distance symbols
 constexpr int kNumCL = 19;  // symbols of the code length code

@@ -6,20 +6,30 @@
 // produced (snappy/build.go:222), so the contract is RFC 1951/1952 validity -- any inflater
 // must return exactly the tar stream -- not the bytes Go's compressor would emit.
 //
-// Parallel axis: the stream is cut into 16 KiB chunks; one wave64 compresses one chunk on its
-// own (four-way hash buckets in LDS, seeded with the previous chunk so that matches reach 32 KiB back) into a
-// dynamic- or fixed-Huffman block (parse and count, build the codes, emit the remembered tokens), ends
-// it with an empty stored block so that the chunk's output is byte aligned (what zlib's
-// Z_SYNC_FLUSH does), and the chunk outputs are concatenated by a second kernel.  A chunk
-// that does not shrink is emitted as a stored block.  Per tile of 64 input positions
-// (lane = position): hash 4 bytes, look up to four candidates up, extend the matches, a scalar greedy
-// parse with one-byte lazy evaluation over the wave's match mask; in the second pass every token-start lane encodes
-// its own token and a prefix sum of the bit lengths places it in the LDS bit buffer.
+// Round 3: hash chains.  The stream is cut into 64 KiB chunks, ONE WORKGROUP (16 waves) per chunk, one DEFLATE
+// block per chunk.  What zlib does one byte after the other is spread over the workgroup as a pipeline of
+// 1 920-byte segments (30 tiles of 64 positions), everything it shares living in LDS (157 KB, one workgroup per CU):
+//   staging   the bytes of the segment (272 ahead) go from HBM into a 32 KiB data ring in LDS: everything below
+//             reads the stream from there -- a search is thousands of scattered 4- and 8-byte reads, which the L1
+//             serves one cache line per cycle and LDS 64 banks per cycle;
+//   index     3-byte hash -> head[4096] and a ring of 32 768 16-bit links (distance to the previous position with
+//             the same hash): inside a tile (64 positions) by ballots, all waves at once; across tiles through
+//             head[], one wave, tile after tile;
+//   search    every position of the segment walks its chain (its own link first, so it only ever sees older
+//             positions) up to kDfDepth candidates within the last 28 800 bytes, four links at a time, and leaves
+//             (length, distance, its byte) in an LDS result word;
+//   parse     wave 0, one segment behind: greedy with one-byte lazy evaluation -- the lanes say where a match
+//             exists and where the next byte matches longer, a scalar loop walks from token to token -> bitmaps;
+//   finish    one more segment behind: symbol counts (LDS atomics), match tokens to an HBM scratch (4 B per
+//             MATCH, not per byte), the two block prices.  Search tiles and finish tiles come from one queue.
+// Then one lane builds the dynamic Huffman codes and the block header (deflate_core.h: the CPU model runs the very
+// same routines), every wave prices its tiles, a scan places them, and all waves encode their tokens into an LDS
+// image of the block (the ring's bytes, spent by then) that is copied out in one coalesced sweep.  A chunk ends
+// with an empty stored block (byte aligned, zlib's Z_SYNC_FLUSH); a second kernel concatenates the chunks.
 //
-// This kernel is integer/LDS work with data-dependent control flow: no MFMA.  Algorithmic bytes: 1 read and
-// <= 1.13 written per input byte; the token scratch adds 4 B out and back per byte.  The measured rate (profiles/)
-// is far below HBM -- instruction issue and LDS latency bound it, and the pass it serves is bound elsewhere (the
-// serial digest of the archive), see DESIGN.md sec. 9.
+// Integer/LDS work with data-dependent control flow: no MFMA.  Algorithmic bytes: 1 read and <= 1.0002 written
+// per input byte (a chunk that does not shrink is stored).  HBM traffic beyond that: the 28 KiB window in front of
+// a chunk is read by two workgroups (x1.44), match tokens out and back (~1 B per input byte on text).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,15 +40,20 @@ namespace snaphash {
 
 namespace {
 
-constexpr uint32_t kHashBits = 11;
-constexpr uint32_t kTab = 1u << kHashBits; // buckets of four candidates, newest first, in one 64-bit word
-constexpr uint32_t kGroup = 16;            // positions that look the table up together, before any of them enters it
+constexpr uint32_t kWaves = 16;
+constexpr uint32_t kThreads = kWaves * 64u;
+constexpr uint32_t kSegTiles = kDfSeg / 64u;                 // 30
+constexpr uint32_t kChunkTiles = kDfChunk / 64u;             // 1024
+constexpr uint32_t kWinSegs = kDfMaxDist / kDfSeg;           // 15
+constexpr uint32_t kRingMask = kDfRing - 1u;
+constexpr uint32_t kHeadN = 1u << kDfHashBits;
+constexpr uint32_t kDataRing = 32768;                        // bytes of the stream kept in LDS
+constexpr uint32_t kDataMask = kDataRing - 1u;
+constexpr uint32_t kLook = 272;                              // bytes in front of the indexed positions that are staged: 258 + 8, in whole 16s
+static_assert(kDfMaxDist + kDfSeg + kLook <= kDataRing, "window + segment + look-ahead live in the data ring");
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-__device__ __forceinline__ uint32_t load32(const uint8_t* p) { return *reinterpret_cast<const u32_unaligned*>(p); }
-__device__ __forceinline__ uint64_t load64(const uint8_t* p) { return *reinterpret_cast<const u64_unaligned*>(p); }
 
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane)
 {
@@ -49,301 +64,554 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane)
     }
     return v;
 }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v, uint32_t lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v, lane), 63);
+}
 
-} // namespace
+// result word of one position: length (9 bits, 0 = no match) | distance << 9 (15 bits) | the byte << 24
+__device__ __forceinline__ uint32_t res_pack(uint32_t len, uint32_t dist, uint32_t byte) { return len | (dist << 9) | (byte << 24); }
 
-constexpr uint32_t kTokStart = 1u << 31, kTokMatch = 1u << 30;
-
-// Per-wave LDS: hash table, bit buffer, symbol counts / codes, scratch of the code construction.
-// The scratch of the code construction is live after the parse, when the table is spent: it lives inside the
-// table's bytes.
 struct HuffScratch {
     uint32_t w[2 * kNumLL];
     uint32_t cnt[260];
     uint16_t parent[2 * kNumLL];
     uint16_t order[kNumLL + 2];
-    // the block header: run-length tokens of the code lengths, the code length code
     uint16_t rle[kNumLL + kNumD + 4];
     uint32_t clfreq[kNumCL + 1];
     uint32_t clcode[kNumCL + 1];
     uint8_t cllen[kNumCL + 1];
     DynHeader hdr;
-    uint32_t hdr_tail; // the header's last, partial word
 };
-struct WaveLds {
-    union {
-        unsigned long long tab[kTab];
-        HuffScratch hs;
-    };
-    uint32_t ob[64];
-    uint32_t freq[320];  // literal/length symbols 0..285, distance symbols at 288..317; after the first pass the
-                         // codes take the counts' place: code << 8 | length, same indexing
-    uint8_t len[320];
-};
-static_assert(sizeof(HuffScratch) <= kTab * sizeof(unsigned long long), "scratch must fit in the table");
 
-__device__ __forceinline__ void put_bits(uint32_t* ob, uint32_t at, uint32_t flushed, uint32_t bits)
+struct ChunkLds {
+    // the block image (emission) overlays the ring and the heads: both are spent when the codes are built
+    union {
+        struct {
+            uint16_t ring[kDfRing];   // 64 KB: distance to the previous position with the same hash, 0 = none
+            uint32_t head[kHeadN];    // 16 KB: newest indexed position + 1 - s0, 0 = none
+        } ix;
+        uint32_t image[(kDfChunk + 16384u) / 4u]; // 80 KB: a block that shrinks is < 64 KiB + framing
+    };
+    uint8_t data[kDataRing + 16];     // 32 KB: the stream around the segment in work, a ring by position; its first 16
+                                      // bytes are mirrored behind its end so that an unaligned read never wraps
+    // search results of three segments in flight (searched | being parsed | being finished); afterwards the scratch of
+    // the code construction and the tile offsets
+    union {
+        uint32_t res[3][kDfSeg];      // 24 KB
+        struct {
+            HuffScratch hs;
+            uint32_t tile_bits[kChunkTiles]; // bits a tile's tokens take, then their exclusive scan
+        } em;
+    };
+    unsigned long long startbits[kChunkTiles]; // 8 KB: positions that begin a token
+    unsigned long long matchbits[kChunkTiles]; // 8 KB: of those, matches
+    uint32_t match_base[kChunkTiles];          // 4 KB: matches in the tiles before this one
+    uint32_t freq[320];   // literal/length symbols 0..285, distance symbols at 288..317; after the codes are built: code << 8 | length
+    uint8_t len[320];
+    unsigned long long lastmask[kSegTiles]; // indexing: the lanes of each tile that are the last of their hash in it
+    uint32_t queue[2];    // work items handed out in the current step (the other counter is reset for the next one)
+    uint32_t fixed_bits, extra_bits, total_bits, dyn_bits, use_dynamic;
+};
+static_assert(sizeof(ChunkLds) <= 160 * 1024, "one workgroup per CU");
+
+__device__ __forceinline__ uint32_t d32(const ChunkLds& L, uint32_t pos) { return *reinterpret_cast<const u32_unaligned*>(L.data + (pos & kDataMask)); }
+__device__ __forceinline__ uint64_t d64(const ChunkLds& L, uint32_t pos) { return *reinterpret_cast<const u64_unaligned*>(L.data + (pos & kDataMask)); }
+
+__device__ __forceinline__ void put_bits(uint32_t* img, uint32_t at, uint32_t bits, uint32_t nbits)
 {
-    const uint32_t widx = (at >> 5) - flushed, sh = at & 31u;
+    if (nbits == 0u) return;
+    const uint32_t widx = at >> 5, sh = at & 31u;
     const uint64_t v = (uint64_t)bits << sh;
-    atomicOr(&ob[widx], (uint32_t)v);
-    if (v >> 32) atomicOr(&ob[widx + 1u], (uint32_t)(v >> 32));
+    atomicOr(&img[widx], (uint32_t)v);
+    if (v >> 32) atomicOr(&img[widx + 1u], (uint32_t)(v >> 32));
 }
 
-// One wave per chunk, four waves (chunks) per workgroup.  in: the stream (readable up to n_in + 8);
-// slots: nchunks * kDeflateSlot bytes; sizes[c]: bytes chunk c produced; toks: one scratch word per input byte.
-// Pass 1 parses the chunk, counts symbols (and prices a fixed-Huffman block) and writes its tokens to `toks`; one
-// lane builds the dynamic codes and the block header (deflate_core.h: the host model runs the same routines);
-// pass 2 re-reads the tokens (each lane its own) and emits a dynamic or a fixed block, whichever is smaller; a
-// chunk that does not shrink is stored.
-__global__ __launch_bounds__(256) void deflate_chunks_kernel(const uint8_t* __restrict__ in, uint64_t n_in,
-                                                             uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes,
-                                                             uint32_t* __restrict__ toks, uint32_t nchunks)
+// ---- staging: bytes [from, from + kDfSeg) of the stream into the data ring (waves 0 and 1, 16 bytes per lane) --------
+// Positions are relative to the staged piece (32 bits: a piece is at most 4 GiB - the library's staging buffers are
+// far smaller); bytes behind n_in read as zero.
+__device__ __forceinline__ void stage_bytes(ChunkLds& L, const uint8_t* __restrict__ in, uint64_t n_in, uint64_t from, uint32_t tid)
 {
-    __shared__ WaveLds s_lds[4];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t c = blockIdx.x * 4u + wave;
-    if (c >= nchunks) return; // whole wave
-    WaveLds& L = s_lds[wave];
-    unsigned long long* tab = L.tab;
-    uint32_t* ob = L.ob;
-    const uint64_t base = (uint64_t)c * kDeflateChunk;
-    const uint32_t len = (uint32_t)((n_in - base < kDeflateChunk) ? (n_in - base) : kDeflateChunk);
-    const uint8_t* src = in + base;
-    uint8_t* dst = slots + (uint64_t)c * kDeflateSlot;
-    uint32_t* dstw = reinterpret_cast<uint32_t*>(dst);
-    uint32_t* tok = toks + base; // one word per position: 0 = inside a match, kTokStart | byte, or kTokMatch | length << 16 | distance
-
-    // ---------------- pass 1: parse, count, remember the tokens ----------------
-    for (uint32_t i = lane; i < 320u; i += 64u) L.freq[i] = 0u;
-    for (uint32_t i = lane; i < kTab; i += 64u) tab[i] = 0ull;
-    __builtin_amdgcn_wave_barrier();
-    // Window: the table is seeded with the previous chunk's positions (when this launch holds it), so a match may
-    // reach up to 32 KiB back across the chunk boundary -- the inflater does not care about block boundaries.
-    // Entries are position + kDeflateChunk + 1 (0 = empty): previous-chunk positions are 1 .. kDeflateChunk.
-    // A bucket is updated tile-wise: every lane reads its bucket, then offers (its entry, the three newest it read);
-    // of the lanes that share a bucket the highest position wins (atomic max: the entry is the most significant field).
-    if (c > 0u) {
-        const uint8_t* prev = src - kDeflateChunk;
-        for (uint32_t p = lane; p < kDeflateChunk; p += 64u) {
-            const uint32_t h = (load32(prev + p) * 0x9E3779B1u) >> (32u - kHashBits);
-            for (uint32_t g = 0; g < 64u / kGroup; ++g) {
-                if (lane / kGroup == g) {
-                    const unsigned long long old = tab[h];
-                    atomicMax(&tab[h], ((unsigned long long)(p + 1u) << 48) | (old >> 16));
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
+    if (tid >= kDfSeg / 16u) return;
+    const uint64_t p = from + (uint64_t)tid * 16u;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p + 16u <= n_in) v = *reinterpret_cast<const uint4*>(in + p);
+    else if (p < n_in) {
+        uint8_t b[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) b[k] = (p + k < n_in) ? in[p + k] : (uint8_t)0;
+        v.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
+        v.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
+        v.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((uint32_t)b[11] << 24);
+        v.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((uint32_t)b[15] << 24);
     }
-    uint32_t fixed_bits = 3u + 7u, extra_bits = 0; // cost of a fixed block / extra bits of the matches (wave-uniform)
-    uint32_t skip_until = 0u;                      // first position not covered by an earlier match
-    for (uint32_t p0 = 0; p0 < len; p0 += 64u) {
-        const uint32_t pos = p0 + lane;
-        const bool valid = pos < len;
-        const bool canmatch = pos + 4u <= len;
-        uint32_t w = 0;
-        if (valid) w = load32(src + pos); // reads at most 3 bytes past the chunk: inside the padded input
-        const uint32_t h = (w * 0x9E3779B1u) >> (32u - kHashBits);
-        unsigned long long cand = 0;
-        for (uint32_t g = 0; g < 64u / kGroup; ++g) { // a group sees what the groups before it in the tile have entered
-            if (canmatch && lane / kGroup == g) {
-                cand = tab[h];
-                atomicMax(&tab[h], ((unsigned long long)(pos + kDeflateChunk + 1u) << 48) | (cand >> 16));
-            }
-            __builtin_amdgcn_wave_barrier();
+    const uint32_t at = (uint32_t)p & kDataMask;
+    *reinterpret_cast<uint4*>(L.data + at) = v;
+    if (at == 0u) *reinterpret_cast<uint4*>(L.data + kDataRing) = v; // the mirror behind the ring's end
+}
+
+// ---- indexing one segment [seg0, seg0 + kDfSeg) ----------------------------------------------------------------
+// link[p] = distance to the nearest earlier position whose three bytes hash alike.  Two phases.
+//   A, all waves, two tiles (64 positions) each, any order: the links INSIDE a tile.  Every lane signs owner[h] with
+//      its lane number; a lane that reads back another signature may have company in its tile (or was overwritten
+//      from another tile: then the ballot below finds it alone); one ballot per such hash gives every member its
+//      predecessor.  A lane with a predecessor writes its link, the first of its hash writes kNeedsHead, and the tile's
+//      mask of "last of its hash" lanes is kept.
+//   B, wave 0, tile after tile: the links ACROSS tiles.  A kNeedsHead lane takes its link from head[h]; a last lane
+//      becomes head[h].  The head read of a tile is in flight while the next tile's hashes are computed.
+constexpr uint32_t kNeedsHead = 0xFFFFu; // (a genuine link is at most 65 534: longer ones are cut, as in the model)
+
+__device__ __forceinline__ void index_tile_inside(ChunkLds& L, uint8_t* __restrict__ owner, uint64_t n_in, uint64_t seg0, uint32_t t, uint64_t c1,
+                                                  uint32_t lane)
+{
+    const uint64_t p = seg0 + (uint64_t)t * 64u + lane;
+    const uint32_t pos = (uint32_t)p;
+    const uint32_t h = df_hash(d32(L, pos));
+    const bool valid = p < c1 && p + 3u <= n_in;
+    const uint8_t me = (uint8_t)lane; // two lanes of ONE tile never carry the same signature: that is all the test below needs
+    if (valid) owner[h] = me;
+    __builtin_amdgcn_wave_barrier();
+    const bool lost = valid && owner[h] != me;
+    int prevlane = -1;
+    bool is_last = valid;
+    uint64_t todo = __ballot(lost);
+    while (todo) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)leader);
+        const uint64_t m = __ballot(valid && h == hl);
+        if (valid && h == hl) {
+            const uint64_t lower = m & ((1ull << lane) - 1ull);
+            prevlane = lower ? 63 - (int)__builtin_clzll(lower) : -1;
+            is_last = (m >> lane) >> 1 == 0ull;
         }
-        uint32_t mlen = 0, dist = 0;
-        if (canmatch && pos >= skip_until) { // a position inside the match that reaches into this tile can start no token
-            const uint32_t maxl = (len - pos < 258u) ? len - pos : 258u;
-            for (uint32_t k = 0; k < 4u; ++k) { // newest first; the longest wins, ties stay with the nearer one
-                const uint32_t e = (uint32_t)(cand >> (48u - 16u * k)) & 0xffffu;
-                if (e == 0u || mlen >= maxl) break;
-                const uint8_t* cs = src + ((int32_t)e - 1 - (int32_t)kDeflateChunk); // an earlier tile or the previous chunk
-                // to beat mlen the candidate must agree in the bytes mlen-3 .. mlen (all inside the chunk: mlen < maxl)
-                if (mlen >= 4u && load32(src + pos + mlen - 3u) != load32(cs + mlen - 3u)) continue;
-                uint32_t l = 0;
-                while (l < maxl) { // eight bytes a step: reads at most 7 bytes past the chunk's last byte
-                    const uint64_t x = load64(src + pos + l) ^ load64(cs + l);
-                    if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; break; }
-                    l += 8u;
-                }
-                if (l > maxl) l = maxl;
-                if (l >= 4u && l > mlen) { mlen = l; dist = (uint32_t)(src + pos - cs); }
-            }
+        todo &= ~m;
+    }
+    if (valid) L.ix.ring[pos & kRingMask] = (uint16_t)(prevlane >= 0 ? lane - (uint32_t)prevlane : kNeedsHead);
+    const uint64_t lastmask = __ballot(is_last);
+    if (lane == 0u) L.lastmask[t] = lastmask;
+}
+
+__device__ __forceinline__ void index_segment_across(ChunkLds& L, uint64_t n_in, uint64_t s0, uint64_t seg0, uint64_t c1, uint32_t lane)
+{
+    bool p_need = false, p_last = false;
+    uint32_t p_h = 0, p_rel1 = 0, p_pos = 0, p_q1 = 0;
+    for (uint32_t t = 0; t <= kSegTiles; ++t) {
+        bool need = false, last = false;
+        uint32_t h = 0, rel1 = 0, pos = 0;
+        if (t < kSegTiles) {
+            const uint64_t p = seg0 + (uint64_t)t * 64u + lane;
+            pos = (uint32_t)p;
+            h = df_hash(d32(L, pos));
+            const bool valid = p < c1 && p + 3u <= n_in;
+            rel1 = (uint32_t)(p - s0) + 1u; // this position + 1, relative to the first indexed one
+            need = valid && L.ix.ring[pos & kRingMask] == kNeedsHead;
+            last = (L.lastmask[t] >> lane) & 1ull;
         }
-        // greedy parse with one-byte lazy evaluation, sequential semantics, on the scalar unit
-        const uint64_t mm_all = __ballot(mlen >= 4u);
+        if (p_need) { // the previous tile: its head values have arrived
+            uint32_t d = p_q1 ? p_rel1 - p_q1 : 0u;
+            if (d >= kNeedsHead) d = 0u;
+            L.ix.ring[p_pos & kRingMask] = (uint16_t)d;
+        }
+        if (p_last) L.ix.head[p_h] = p_rel1;
+        // this tile's head reads: behind the previous tile's head writes (one wave's LDS operations keep their order)
+        uint32_t q1 = 0;
+        if (need) q1 = L.ix.head[h];
+        p_need = need; p_last = last; p_h = h; p_rel1 = rel1; p_pos = pos; p_q1 = q1;
+    }
+}
+
+// ---- searcher: the best match of one position ------------------------------------------------------------------
+__device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uint8_t* __restrict__ in, uint64_t n_in, uint64_t p64, uint64_t c1)
+{
+    if (p64 >= c1) return 0u;
+    const uint32_t p = (uint32_t)p64;
+    const uint32_t byte = L.data[p & kDataMask];
+    const uint32_t maxl = (c1 - p64 < 258u) ? (uint32_t)(c1 - p64) : 258u;
+    if (maxl < kDfMinMatch || p64 + 3u > n_in) return res_pack(0u, 0u, byte);
+    // The walk in batches of four links: the links of a batch come out of LDS one after the other, the four candidates'
+    // check words (the four bytes ending at the best length the batch started with -- a candidate that differs there
+    // cannot be longer) travel together, then the survivors are extended.  Exactly the serial walk's result: the
+    // check only ever spares work.
+    uint32_t best = kDfMinMatch - 1u, bdist = 0u, left = kDfDepth;
+    uint32_t cur = p;
+    bool more = true;
+    while (more && left) {
+        uint32_t c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0, ncand = 0;
+#define SNAPHASH_DF_LINK(dst)                                                       \
+        if (more && ncand < left) {                                                 \
+            const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
+            if (d_ == 0u || p - (cur - d_) > kDfMaxDist) more = false;              \
+            else { cur -= d_; dst = cur; ++ncand; }                                 \
+        }
+        SNAPHASH_DF_LINK(c0_) SNAPHASH_DF_LINK(c1_) SNAPHASH_DF_LINK(c2_) SNAPHASH_DF_LINK(c3_)
+#undef SNAPHASH_DF_LINK
+        const uint32_t off = best >= 3u ? best - 3u : 0u;
+        const uint32_t mine = d32(L, p + off);
+        // the candidates' check words come through L1/L2 (the texture path), not from the data ring: the ring's LDS
+        // pipe is what bounds the walk (links, this position's words, the extensions), and the two paths run side by
+        // side (12.6 instead of 14.5 ms per 64 MiB of text)
+        const uint8_t* gb = in + (p64 - p);
+        const uint32_t k0 = *reinterpret_cast<const u32_unaligned*>(gb + c0_ + off), k1 = *reinterpret_cast<const u32_unaligned*>(gb + c1_ + off),
+                       k2 = *reinterpret_cast<const u32_unaligned*>(gb + c2_ + off), k3 = *reinterpret_cast<const u32_unaligned*>(gb + c3_ + off);
+#define SNAPHASH_DF_EVAL(k, cand, chk)                                                                         \
+        if (k < ncand && left) {                                                                                \
+            --left;                                                                                             \
+            bool go = true;                                                                                     \
+            if (best >= 3u) go = (off == best - 3u) ? (chk == mine) : (d32(L, cand + best - 3u) == d32(L, p + best - 3u)); \
+            if (go) {                                                                                           \
+                uint32_t l = 0;                                                                                 \
+                while (l < maxl) { /* eight bytes a step */                                                     \
+                    const uint64_t x = d64(L, p + l) ^ d64(L, cand + l);                                        \
+                    if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; break; }                                   \
+                    l += 8u;                                                                                    \
+                }                                                                                               \
+                if (l > maxl) l = maxl;                                                                         \
+                if (l > best) {                                                                                 \
+                    best = l;                                                                                   \
+                    bdist = p - cand;                                                                           \
+                    if (l >= kDfNice || l >= maxl) left = 0u;                                                   \
+                    else if (l >= kDfGood && left > kDfDepth / 4u) left = kDfDepth / 4u;                        \
+                }                                                                                               \
+            }                                                                                                   \
+        }
+        SNAPHASH_DF_EVAL(0u, c0_, k0) SNAPHASH_DF_EVAL(1u, c1_, k1) SNAPHASH_DF_EVAL(2u, c2_, k2) SNAPHASH_DF_EVAL(3u, c3_, k3)
+#undef SNAPHASH_DF_EVAL
+    }
+    if (best == 3u && bdist > kDfTooFar) best = 0u;
+    return best >= kDfMinMatch ? res_pack(best, bdist, byte) : res_pack(0u, 0u, byte);
+}
+
+// ---- parser (wave 0): which positions of a segment begin a token, which of those are matches ----------------------
+// Greedy with one-byte lazy evaluation, tile by tile: the lanes say in parallel where a match exists and where the
+// next byte matches longer; the walk from token to token is a scalar loop.  skip_until: first chunk-relative position
+// not covered by an earlier match; nmatch: matches so far.
+__device__ __forceinline__ void parse_segment(ChunkLds& L, const uint32_t* __restrict__ res, uint32_t seg_rel0, uint32_t len, uint32_t lane,
+                                              uint32_t& skip_until, uint32_t& nmatch)
+{
+    uint32_t r_next = res[lane]; // the next tile's result words are on their way while this tile is walked
+    for (uint32_t t = 0; t < kSegTiles; ++t) {
+        const uint32_t p0 = seg_rel0 + t * 64u;
+        if (p0 >= len) break;
+        const uint32_t tile = p0 >> 6;
+        const uint32_t mlen = r_next & 0x1ffu;
+        if (t + 1u < kSegTiles) r_next = res[(t + 1u) * 64u + lane];
         const uint32_t tile_n = (len - p0 < 64u) ? len - p0 : 64u;
-        uint64_t start_mask = 0, match_mask = 0;
+        // lane i+1's length: wave_shl:1 (DPP, no LDS traffic); lane 63 reads 0
+        const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlen, 0x130, 0xf, 0xf, false);
+        const bool has = mlen >= kDfMinMatch && lane < tile_n;
+        const bool lazy = has && lane + 1u < tile_n && next > mlen; // the next byte matches longer: this one goes out as a literal
+        const uint64_t mm_all = __ballot(has);
+        const uint64_t take = __ballot(has && !lazy);                // a token that starts here is a match
+        const uint32_t step = (has && !lazy) ? mlen : 1u;            // where the token that starts here ends
+        const uint64_t inside = (tile_n == 64u) ? ~0ull : ((1ull << tile_n) - 1ull);
+        uint64_t start_mask = 0;
         uint32_t rel = (skip_until > p0) ? skip_until - p0 : 0u;
-        while (rel < tile_n) {
+        while (rel < tile_n) { // from token to token; runs of literals in one stride
             const uint64_t mm = mm_all & (~0ull << rel);
             if (mm == 0ull) {
-                start_mask |= (~0ull << rel) & ((tile_n == 64u) ? ~0ull : ((1ull << tile_n) - 1ull));
+                start_mask |= (~0ull << rel) & inside;
                 rel = tile_n;
                 break;
             }
             const uint32_t f = (uint32_t)__builtin_ctzll(mm);
-            if (f > rel) start_mask |= (~0ull << rel) & ((1ull << f) - 1ull);
-            start_mask |= 1ull << f;
-            const uint32_t ml = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)f);
-            // lazy evaluation (as zlib from level 4 up): a longer match one byte later wins, this byte goes out as a literal
-            if (f + 1u < tile_n && (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)(f + 1u)) > ml) {
-                rel = f + 1u;
-                continue;
-            }
-            match_mask |= 1ull << f;
-            rel = f + ml;
+            start_mask |= (~0ull << rel) & ((2ull << f) - 1ull); // literals rel .. f-1 and the token at f
+            rel = f + (uint32_t)__builtin_amdgcn_readlane((int)step, (int)f);
         }
         skip_until = p0 + rel;
-        const bool my_start = (start_mask >> lane) & 1ull;
-        const bool my_match = (match_mask >> lane) & 1ull;
-        uint32_t ls = w & 0xffu, le = 0, lv = 0, ds = 0, de = 0, dv = 0;
-        if (my_match) { len_symbol(mlen, ls, le, lv); dist_symbol(dist, ds, de, dv); }
-        uint32_t fb = 0, eb = 0, t = 0;
-        if (my_start) {
-            atomicAdd(&L.freq[ls], 1u);
-            fb = fixed_ll_bits(ls);
-            t = kTokStart | ls;
-            if (my_match) {
-                atomicAdd(&L.freq[288u + ds], 1u);
-                fb += 5u;
-                eb = le + de;
-                t = kTokStart | kTokMatch | (mlen << 16) | dist;
+        const uint64_t match_mask = start_mask & take;
+        if (lane == 0u) {
+            L.startbits[tile] = start_mask;
+            L.matchbits[tile] = match_mask;
+            L.match_base[tile] = nmatch;
+        }
+        nmatch += (uint32_t)__builtin_popcountll(match_mask);
+    }
+}
+
+// ---- finisher: the tokens of one parsed tile -> symbol counts, match tokens to the scratch, block prices -------------
+__device__ __forceinline__ void finish_tile(ChunkLds& L, const uint32_t* __restrict__ res, uint32_t t, uint32_t tile, uint32_t lane,
+                                            uint32_t& fixed_lane, uint32_t& extra_lane, uint32_t* __restrict__ tok)
+{
+    const uint32_t r = res[t * 64u + lane];
+    const uint32_t mlen = r & 0x1ffu, dist = (r >> 9) & 0x7fffu, byte = r >> 24;
+    const uint64_t start_mask = L.startbits[tile], match_mask = L.matchbits[tile];
+    const bool my_start = (start_mask >> lane) & 1ull;
+    const bool my_match = (match_mask >> lane) & 1ull;
+    if (!my_start) return;
+    uint32_t ls = byte, le = 0, lv = 0, ds = 0, de = 0, dv = 0;
+    if (my_match) { len_symbol(mlen, ls, le, lv); dist_symbol(dist, ds, de, dv); }
+    atomicAdd(&L.freq[ls], 1u);
+    fixed_lane += fixed_ll_bits(ls);
+    if (my_match) {
+        atomicAdd(&L.freq[288u + ds], 1u);
+        fixed_lane += 5u;
+        extra_lane += le + de;
+        const uint32_t rank = (uint32_t)__builtin_popcountll(match_mask & ((1ull << lane) - 1ull));
+        tok[L.match_base[tile] + rank] = mlen | (dist << 16);
+    }
+}
+
+// code and length of the token that starts at this lane's position (part A = literal/length code + extra bits,
+// part B = distance code + extra bits; each at most 28 bits)
+__device__ __forceinline__ void token_bits(const ChunkLds& L, bool dynamic, bool my_start, bool my_match, uint32_t byte, uint32_t t, uint32_t& ba,
+                                           uint32_t& na, uint32_t& bb, uint32_t& nb)
+{
+    ba = na = bb = nb = 0u;
+    if (!my_start) return;
+    if (dynamic) {
+        uint32_t ls = byte, le = 0, lv = 0, ds = 0, de = 0, dv = 0;
+        if (my_match) { len_symbol(t & 0x1ffu, ls, le, lv); dist_symbol(t >> 16, ds, de, dv); }
+        const uint32_t ca = L.freq[ls];
+        ba = (ca >> 8) | (lv << (ca & 0xffu));
+        na = (ca & 0xffu) + le;
+        if (my_match) {
+            const uint32_t cb = L.freq[288u + ds];
+            bb = (cb >> 8) | (dv << (cb & 0xffu));
+            nb = (cb & 0xffu) + de;
+        }
+    } else if (my_match) {
+        enc_match(t & 0x1ffu, t >> 16, ba, na);
+    } else {
+        enc_literal(byte, ba, na);
+    }
+}
+
+} // namespace
+
+// One workgroup per chunk.  in: the staged stream (readable up to n_in + 8); slots: nchunks * kDeflateSlot bytes;
+// sizes[c]: bytes chunk c produced; toks: nchunks * kDeflateTokWords words of scratch (the chunk's match tokens).
+__global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __restrict__ in, uint64_t n_in, uint8_t* __restrict__ slots,
+                                                              uint32_t* __restrict__ sizes, uint32_t* __restrict__ toks, uint32_t nchunks)
+{
+    __shared__ ChunkLds L;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x;
+    if (c >= nchunks) return;
+    const uint64_t c0 = (uint64_t)c * kDfChunk;
+    const uint32_t len = (uint32_t)((n_in - c0 < kDfChunk) ? (n_in - c0) : kDfChunk);
+    const uint64_t c1 = c0 + len;
+    const uint32_t nwin = c0 >= kDfMaxDist ? kWinSegs : 0u; // c0 is a multiple of 64 KiB: all of the window or none
+    const uint64_t s0 = c0 - (uint64_t)nwin * kDfSeg;
+    const uint32_t nseg = (len + kDfSeg - 1u) / kDfSeg;
+    uint8_t* dst = slots + (uint64_t)c * kDeflateSlot;
+    uint32_t* tok = toks + (uint64_t)c * kDeflateTokWords;
+
+    for (uint32_t i = threadIdx.x; i < kHeadN; i += kThreads) L.ix.head[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < 320u; i += kThreads) L.freq[i] = 0u;
+    if (threadIdx.x < kLook / 16u) { // the first bytes in front of the staging's stride
+        const uint64_t p = s0 + (uint64_t)threadIdx.x * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p + 16u <= n_in) v = *reinterpret_cast<const uint4*>(in + p);
+        else for (uint32_t k = 0; k < 16u; ++k) if (p + k < n_in) reinterpret_cast<uint8_t*>(&v)[k] = in[p + k];
+        const uint32_t at = (uint32_t)p & kDataMask;
+        *reinterpret_cast<uint4*>(L.data + at) = v;
+        if (at == 0u) *reinterpret_cast<uint4*>(L.data + kDataRing) = v;
+    }
+    if (threadIdx.x == 0u) { L.queue[0] = 0u; L.queue[1] = 0u; }
+    __syncthreads();
+
+    // ---------------- the pipeline, per step i ----------------
+    //   all waves   stage the bytes of segment i (kLook ahead); index it inside its tiles (two tiles per wave)
+    //   then        wave 0: the links across tiles | the others: finish segment j - 2 (tiles from a queue)
+    //   then        waves 1-15: search chunk segment j = i - nwin (30 tiles from a queue) | wave 0: parse segment j - 1
+    uint32_t skip_until = 0, nmatch = 0, fixed_lane = 0, extra_lane = 0;
+    const uint32_t steps = nwin + nseg + 2u;
+#if defined(SNAPHASH_DEFLATE_STAMPS)
+    uint64_t t_ins = 0, t_par = 0, t_sea = 0, t_fin = 0, t_all0 = __builtin_amdgcn_s_memtime();
+#define STAMP(acc, code) { const uint64_t s_ = __builtin_amdgcn_s_memtime(); code; acc += __builtin_amdgcn_s_memtime() - s_; }
+#else
+#define STAMP(acc, code) { code; }
+#endif
+    for (uint32_t i = 0; i < steps; ++i) {
+        const bool chunk_step = i >= nwin;
+        const uint32_t j = i - nwin; // the chunk segment this step indexes and searches (meaningful when chunk_step)
+        const bool do_finish = chunk_step && j >= 2u && j - 2u < nseg;
+        if (i < nwin + nseg) {
+            const uint64_t seg0 = s0 + (uint64_t)i * kDfSeg;
+            stage_bytes(L, in, n_in, seg0 + kLook, threadIdx.x);
+            __syncthreads();
+            // the result buffer this step's search will fill is free until then: the owners' signatures live there
+            uint8_t* owner = reinterpret_cast<uint8_t*>(L.res[(chunk_step ? j : i) % 3u]);
+            static_assert(sizeof(L.res[0]) >= kHeadN, "the signatures of one segment fit a result buffer");
+            STAMP(t_ins, for (uint32_t t = wave; t < kSegTiles; t += kWaves) index_tile_inside(L, owner, n_in, seg0, t, c1, lane));
+            __syncthreads();
+            if (wave == 0u) {
+                __builtin_amdgcn_s_setprio(3);
+                STAMP(t_ins, index_segment_across(L, n_in, s0, seg0, c1, lane));
+                __builtin_amdgcn_s_setprio(0);
             }
         }
-        if (valid) tok[pos] = t;
-        const uint32_t tf = wave_scan_incl(fb, lane), te = wave_scan_incl(eb, lane);
-        fixed_bits += (uint32_t)__builtin_amdgcn_readlane((int)tf, 63);
-        extra_bits += (uint32_t)__builtin_amdgcn_readlane((int)te, 63);
+        // meanwhile (and in the draining steps): the tokens of segment j - 2
+        if (do_finish) {
+            for (;;) {
+                uint32_t item = 0;
+                if (lane == 0u) item = atomicAdd(&L.queue[0], 1u);
+                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+                if (item >= kSegTiles) break;
+                const uint32_t rel0 = (j - 2u) * kDfSeg + item * 64u;
+                if (rel0 < len) STAMP(t_fin, finish_tile(L, L.res[(j - 2u) % 3u], item, rel0 >> 6, lane, fixed_lane, extra_lane, tok));
+            }
+        }
+        __syncthreads();
+        if (!chunk_step) continue; // the window in front of the chunk is only indexed
+        if (wave == 0u) { // the one serial job of the step; the fifteen others search two tiles each meanwhile
+            if (j >= 1u && j - 1u < nseg) {
+                __builtin_amdgcn_s_setprio(3);
+                STAMP(t_par, parse_segment(L, L.res[(j - 1u) % 3u], (j - 1u) * kDfSeg, len, lane, skip_until, nmatch));
+                __builtin_amdgcn_s_setprio(0);
+            }
+        } else if (j < nseg) {
+            for (;;) {
+                uint32_t item = 0;
+                if (lane == 0u) item = atomicAdd(&L.queue[1], 1u);
+                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+                if (item >= kSegTiles) break;
+                STAMP(t_sea, L.res[j % 3u][item * 64u + lane] = search_position(L, in, n_in, c0 + (uint64_t)j * kDfSeg + item * 64u + lane, c1));
+            }
+        }
+        if (threadIdx.x == 0u) L.queue[0] = 0u; // the finish queue: handed out again only behind the next barriers
+        __syncthreads();
+        if (threadIdx.x == 0u) L.queue[1] = 0u; // the search queue: likewise
     }
+    // the block prices: every wave holds a share
+    {
+        const uint32_t f = wave_sum(fixed_lane, lane), e = wave_sum(extra_lane, lane);
+        if (threadIdx.x == 0u) { L.fixed_bits = 3u + 7u; L.extra_bits = 0u; }
+        __syncthreads();
+        if (lane == 0u) { atomicAdd(&L.fixed_bits, f); atomicAdd(&L.extra_bits, e); }
+    }
+#if defined(SNAPHASH_DEFLATE_STAMPS)
+    const uint64_t t_pipe = __builtin_amdgcn_s_memtime() - t_all0;
+    if (c == 37u && lane == 0u && wave <= 1u)
+        printf("chunk %u wave %u: pipeline %llu cycles; insert %llu parse %llu search %llu finish %llu\n", c, wave, (unsigned long long)t_pipe,
+               (unsigned long long)t_ins, (unsigned long long)t_par, (unsigned long long)t_sea, (unsigned long long)t_fin);
+    const uint64_t t_tail0 = __builtin_amdgcn_s_memtime();
+#endif
+    __threadfence_block(); // the match tokens in the scratch are read back by every wave of this workgroup
+    __syncthreads();
 
-    // ---------------- the codes and the header: one lane, sequential and deterministic (the host model runs the same routines) ----------------
-    __builtin_amdgcn_wave_barrier();
-    HuffScratch& S = L.hs;
-    if (lane == 0u) {
+    // ---------------- the codes and the header: one lane, sequential and deterministic (the CPU model runs the same routines) ----------------
+    HuffScratch& S = L.em.hs;
+    if (threadIdx.x == 0u) {
         L.freq[256] += 1u; // end of block
         if (L.freq[288] == 0u) L.freq[288] = 1u; // at least two distance codes, as zlib sends
         if (L.freq[289] == 0u) L.freq[289] = 1u;
         huff_lengths(L.freq, kNumLL, (uint32_t)kMaxBits, L.len, S.w, S.parent, S.order, S.cnt);
         huff_lengths(L.freq + 288, kNumD, (uint32_t)kMaxBits, L.len + 288, S.w, S.parent, S.order, S.cnt);
         build_dyn_header(L.len, L.len + 288, S.rle, S.clfreq, S.cllen, S.clcode, S.w, S.parent, S.order, S.cnt, S.hdr);
+        uint32_t db = S.hdr.bits + L.extra_bits;
+        for (uint32_t k = 0; k < 318u; ++k)
+            if (k < (uint32_t)kNumLL || k >= 288u) db += L.freq[k] * (uint32_t)L.len[k];
+        L.dyn_bits = db;
+        L.use_dynamic = db < L.fixed_bits + L.extra_bits ? 1u : 0u;
     }
-    __builtin_amdgcn_wave_barrier();
-    uint32_t db = 0; // bits a dynamic block spends on the symbols
-    for (uint32_t i = lane; i < 318u; i += 64u)
-        if (i < (uint32_t)kNumLL || i >= 288u) db += L.freq[i] * (uint32_t)L.len[i];
-    const uint32_t hdr_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.hdr.bits);
-    const uint32_t dyn_bits = hdr_bits + extra_bits + (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(db, lane), 63);
-    fixed_bits += extra_bits;
-    const bool dynamic = dyn_bits < fixed_bits;
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0u) {
-        if (dynamic) {
-            // the counts are spent: the codes go where they were
-            huff_codes(L.len, kNumLL, L.freq, S.cnt);
-            huff_codes(L.len + 288, kNumD, L.freq + 288, S.cnt);
-            // the header goes straight to the slot, whole words; its partial last word opens the bit buffer
-            uint64_t acc = 0;
-            uint32_t nacc = 0, widx = 0;
-            write_dyn_header(S.hdr, S.rle, S.cllen, S.clcode, [&](uint32_t bits, uint32_t nb) {
-                acc |= (uint64_t)bits << nacc;
-                nacc += nb;
-                if (nacc >= 32u) { dstw[widx++] = (uint32_t)acc; acc >>= 32; nacc -= 32u; }
-            });
-            S.hdr_tail = (uint32_t)acc;
-        } else {
-            S.hdr_tail = 2u; // BFINAL=0, BTYPE=01: bits 0,1,0 LSB first
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint32_t bitpos = dynamic ? hdr_bits : 3u;
-    uint32_t flushed = bitpos >> 5;
-    ob[lane] = (lane == 0u) ? S.hdr_tail : 0u;
-    __builtin_amdgcn_wave_barrier();
-
-    // ---------------- pass 2: emit the remembered tokens ----------------
-    bool overflow = false;
-    for (uint32_t p0 = 0; p0 < len; p0 += 64u) {
-        const uint32_t pos = p0 + lane;
-        const uint32_t t = (pos < len) ? tok[pos] : 0u;
-        // part A = literal/length code + its extra bits, part B = distance code + its extra bits (each <= 32 bits)
-        uint32_t ba = 0, na = 0, bb = 0, nbb = 0;
-        if (t & kTokStart) {
-            if (dynamic) {
-                uint32_t ls = t & 0x1ffu, le = 0, lv = 0, ds = 0, de = 0, dv = 0;
-                if (t & kTokMatch) { len_symbol((t >> 16) & 0x1ffu, ls, le, lv); dist_symbol(t & 0xffffu, ds, de, dv); }
-                const uint32_t ca = L.freq[ls];
-                ba = (ca >> 8) | (lv << (ca & 0xffu));
-                na = (ca & 0xffu) + le;
-                if (t & kTokMatch) {
-                    const uint32_t cb = L.freq[288u + ds];
-                    bb = (cb >> 8) | (dv << (cb & 0xffu));
-                    nbb = (cb & 0xffu) + de;
-                }
-            } else if (t & kTokMatch) {
-                enc_match((t >> 16) & 0x1ffu, t & 0xffffu, ba, na);
-            } else {
-                enc_literal(t & 0xffu, ba, na);
-            }
-        }
-        const uint32_t nb = na + nbb;
-        const uint32_t incl = wave_scan_incl(nb, lane);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (nb) {
-            const uint32_t at = bitpos + incl - nb;
-            put_bits(ob, at, flushed, ba);
-            if (nbb) put_bits(ob, at + na, flushed, bb);
-        }
-        bitpos += total;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t done = (bitpos >> 5) - flushed; // complete words in the buffer (< 34)
-        const uint32_t mine = ob[lane];
-        const uint32_t carry = ob[done];               // the partial word (uniform address: broadcast)
-        __builtin_amdgcn_wave_barrier();
-        if ((flushed + done) * 4u + 64u > kDeflateSlot) overflow = true; // only a chunk that ends up stored comes here
-        if (lane < done && !overflow) dstw[flushed + lane] = mine;
-        ob[lane] = (lane == 0u) ? carry : 0u;
-        __builtin_amdgcn_wave_barrier();
-        flushed += done;
-    }
-
-    // end of block (fixed: seven 0 bits; dynamic: the code of symbol 256), then an empty stored block: 3 header
-    // bits, pad to a byte, LEN=0, NLEN=0xFFFF -- the chunk's output ends on a byte boundary
-    if (dynamic) {
-        const uint32_t ce = L.freq[256];
-        if (lane == 0u) put_bits(ob, bitpos, flushed, ce >> 8);
-        bitpos += ce & 0xffu;
-    } else {
-        bitpos += 7u;
-    }
-    bitpos += 3u;
-    bitpos = (bitpos + 7u) & ~7u;
-    if (lane == 0u) {
-        put_bits(ob, bitpos, flushed, 0xFFFF0000u);
-    }
-    bitpos += 32u;
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nbytes = bitpos >> 3;
-    const uint32_t words = ((bitpos + 31u) >> 5) - flushed;
-    if (lane < words && !overflow) dstw[flushed + lane] = ob[lane];
-
-    if (overflow || nbytes >= len + 5u) { // did not shrink: one stored block (BFINAL=0, BTYPE=00 in a whole byte; LEN; ~LEN; the bytes)
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0u) {
+    __syncthreads();
+#if defined(SNAPHASH_DEFLATE_STAMPS)
+    if (c == 37u && threadIdx.x == 0u) printf("chunk %u: codes %llu cycles\n", c, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_tail0));
+#endif
+    const bool dynamic = L.use_dynamic != 0u;
+    const uint32_t body_bits = dynamic ? L.dyn_bits : L.fixed_bits + L.extra_bits; // header, tokens and end-of-block
+    // + the empty stored block: 3 header bits, pad to a byte, LEN = 0, NLEN = 0xFFFF
+    const uint32_t nbytes = ((body_bits + 3u + 7u) >> 3) + 4u;
+    const uint32_t stored_bytes = deflate_stored_size(len);
+    const bool stored = nbytes >= stored_bytes;
+    if (stored) { // did not shrink: stored blocks (BFINAL=0, BTYPE=00 in a whole byte; LEN; ~LEN; the bytes).  LEN is 16 bits:
+                  // a full 64 KiB chunk goes out as two blocks of 32 KiB
+        const uint32_t first = len > 65535u ? 32768u : len;
+        if (threadIdx.x == 0u) {
             dst[0] = 0u;
-            dst[1] = (uint8_t)len; dst[2] = (uint8_t)(len >> 8);
-            dst[3] = (uint8_t)~len; dst[4] = (uint8_t)(~len >> 8);
+            dst[1] = (uint8_t)first; dst[2] = (uint8_t)(first >> 8);
+            dst[3] = (uint8_t)~first; dst[4] = (uint8_t)(~first >> 8);
+            if (first < len) {
+                const uint32_t rest = len - first;
+                uint8_t* h2 = dst + 5u + first;
+                h2[0] = 0u;
+                h2[1] = (uint8_t)rest; h2[2] = (uint8_t)(rest >> 8);
+                h2[3] = (uint8_t)~rest; h2[4] = (uint8_t)(~rest >> 8);
+            }
+            sizes[c] = stored_bytes;
         }
+        const uint8_t* src = in + c0; // 16-byte aligned (c0 is a multiple of 64 KiB)
         const uint32_t nw = len >> 2;
-        for (uint32_t i = lane; i < nw; i += 64u)
-            *reinterpret_cast<u32_unaligned*>(dst + 5u + 4u * i) = *reinterpret_cast<const uint32_t*>(src + 4u * i);
-        for (uint32_t i = (nw << 2) + lane; i < len; i += 64u) dst[5u + i] = src[i];
-        if (lane == 0u) sizes[c] = len + 5u;
-    } else if (lane == 0u) {
-        sizes[c] = nbytes;
+        for (uint32_t i = threadIdx.x; i < nw; i += kThreads) {
+            const uint32_t at = 4u * i;
+            *reinterpret_cast<u32_unaligned*>(dst + 5u + at + (at >= first ? 5u : 0u)) = *reinterpret_cast<const uint32_t*>(src + at);
+        }
+        for (uint32_t i = (nw << 2) + threadIdx.x; i < len; i += kThreads) dst[5u + i + (i >= first ? 5u : 0u)] = src[i];
+        return;
     }
+
+    // ---------------- emission: price the tiles, place them, encode into the LDS image, copy out ----------------
+    const uint32_t ntiles = (len + 63u) >> 6;
+    if (threadIdx.x == 0u && dynamic) { // the counts are spent: the codes go where they were
+        huff_codes(L.len, kNumLL, L.freq, S.cnt);
+        huff_codes(L.len + 288, kNumD, L.freq + 288, S.cnt);
+    }
+    const uint32_t img_words = (nbytes + 3u) >> 2;
+    for (uint32_t i = threadIdx.x; i < img_words + 2u; i += kThreads) L.image[i] = 0u; // the ring and the heads are spent
+    __syncthreads();
+    for (uint32_t tile = wave; tile < ntiles; tile += kWaves) { // pass A: bits per tile
+        const uint64_t sm = L.startbits[tile], mk = L.matchbits[tile];
+        const bool my_start = (sm >> lane) & 1ull, my_match = (mk >> lane) & 1ull;
+        const uint32_t pos = tile * 64u + lane;
+        const uint32_t byte = pos < len ? in[c0 + pos] : 0u;
+        uint32_t t = 0;
+        if (my_match) t = tok[L.match_base[tile] + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull))];
+        uint32_t ba, na, bb, nb;
+        token_bits(L, dynamic, my_start, my_match, byte, t, ba, na, bb, nb);
+        const uint32_t total = wave_sum(na + nb, lane);
+        if (lane == 0u) L.em.tile_bits[tile] = total;
+    }
+    __syncthreads();
+    if (wave == 0u) { // exclusive scan of the tile sizes, the header's bits in front
+        uint32_t run = dynamic ? S.hdr.bits : 3u;
+        for (uint32_t t0 = 0; t0 < ntiles; t0 += 64u) {
+            const uint32_t v = (t0 + lane < ntiles) ? L.em.tile_bits[t0 + lane] : 0u;
+            const uint32_t incl = wave_scan_incl(v, lane);
+            if (t0 + lane < ntiles) L.em.tile_bits[t0 + lane] = run + incl - v;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0u) L.total_bits = run; // where the end-of-block code goes
+    }
+    if (threadIdx.x == 64u) { // meanwhile: the block header
+        if (dynamic) {
+            uint32_t at = 0;
+            write_dyn_header(S.hdr, S.rle, S.cllen, S.clcode, [&](uint32_t bits, uint32_t nb) { put_bits(L.image, at, bits, nb); at += nb; });
+        } else {
+            put_bits(L.image, 0u, 2u, 3u); // BFINAL=0, BTYPE=01
+        }
+    }
+    __syncthreads();
+    for (uint32_t tile = wave; tile < ntiles; tile += kWaves) { // pass B: encode
+        const uint64_t sm = L.startbits[tile], mk = L.matchbits[tile];
+        const bool my_start = (sm >> lane) & 1ull, my_match = (mk >> lane) & 1ull;
+        const uint32_t pos = tile * 64u + lane;
+        const uint32_t byte = pos < len ? in[c0 + pos] : 0u;
+        uint32_t t = 0;
+        if (my_match) t = tok[L.match_base[tile] + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull))];
+        uint32_t ba, na, bb, nb;
+        token_bits(L, dynamic, my_start, my_match, byte, t, ba, na, bb, nb);
+        const uint32_t incl = wave_scan_incl(na + nb, lane);
+        const uint32_t at = L.em.tile_bits[tile] + incl - (na + nb);
+        put_bits(L.image, at, ba, na);
+        put_bits(L.image, at + na, bb, nb);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) { // end of block, then the empty stored block that byte-aligns the chunk
+        uint32_t at = L.total_bits;
+        if (dynamic) { const uint32_t ce = L.freq[256]; put_bits(L.image, at, ce >> 8, ce & 0xffu); at += ce & 0xffu; }
+        else at += 7u;
+        at += 3u;
+        at = (at + 7u) & ~7u;
+        put_bits(L.image, at, 0xFFFF0000u, 32u);
+        sizes[c] = (at >> 3) + 4u;
+    }
+    __syncthreads();
+    uint32_t* dstw = reinterpret_cast<uint32_t*>(dst); // slots are 64-byte aligned
+    for (uint32_t i = threadIdx.x; i < img_words; i += kThreads) dstw[i] = L.image[i];
+#if defined(SNAPHASH_DEFLATE_STAMPS)
+    if (c == 37u && threadIdx.x == 0u) printf("chunk %u: codes + emission %llu ticks\n", c, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_tail0));
+#endif
 }
 
 // Concatenates the chunk outputs: chunk c's sizes[c] bytes go to out + prefix[c].
@@ -366,8 +634,7 @@ hipError_t launch_deflate_chunks(const uint8_t* d_in, uint64_t n_in, uint8_t* d_
                                  uint32_t nchunks, hipStream_t s)
 {
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(deflate_chunks_kernel, dim3((nchunks + 3u) / 4u), dim3(256), 0, s, d_in, n_in, d_slots, d_sizes, d_toks,
-                       nchunks);
+    hipLaunchKernelGGL(deflate_chunks_kernel, dim3(nchunks), dim3(1024), 0, s, d_in, n_in, d_slots, d_sizes, d_toks, nchunks);
     return hipGetLastError();
 }
 

@@ -171,13 +171,15 @@ __global__ __launch_bounds__(64) SNAPHASH_WIDE_ATTR void sha512_wide_kernel(cons
     }
 }
 
+#if defined(SNAPHASH_EXPERIMENT_WIDE_DIRECT)
 // ---------------------------------------------------------------------------
 // WIDE, direct form: as above without the LDS tile.  Every lane fetches ITS OWN 128-byte block with eight
 // global_load_dwordx4 (one cache line per lane, all of it used by the eight loads back to back: the HBM traffic
 // stays 1x, the address unit sees 64 lines per instruction -- ~0.5 k cycles of it per 16 k-cycle block).  No tile,
 // no cooperative pointers, no register prefetch: 56 VGPRs less, no LDS, so 5 waves per SIMD instead of 3 and the
-// other waves hide the load latency.  For the saturated regime (>= ~64 k streams), where occupancy is what the
-// dependent chain of a round needs.
+// other waves hide the load latency.  EXPERIMENT (make WIDE_DIRECT=1, then SNAPHASH_WIDE_FORM=1|2|3 at run time):
+// bit-exact and no faster at 5, 6 or 8 waves per SIMD -- the saturated regime is bound by the vector unit's rate for
+// this instruction mix, not by latency (profiles/r03_wide_saturated_explained.txt).
 // ---------------------------------------------------------------------------
 template <int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void sha512_wide_direct_kernel(
@@ -229,6 +231,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
     }
 }
+
+#endif // SNAPHASH_EXPERIMENT_WIDE_DIRECT
 
 // ---------------------------------------------------------------------------
 // SPLIT kernel: for the stream-starved regime (fewer streams than the chip has
@@ -717,11 +721,13 @@ hipError_t launch_wide(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uin
 {
     if (njobs == 0) return hipSuccess;
     const uint32_t grid = (njobs + 63u) / 64u;
-    static const int form = [] { const char* e = getenv("SNAPHASH_WIDE_FORM"); return e ? atoi(e) : 0; }(); // experiment switch
-    if (form == 1) hipLaunchKernelGGL(sha512_wide_direct_kernel<5>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
-    else if (form == 2) hipLaunchKernelGGL(sha512_wide_direct_kernel<6>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
-    else if (form == 3) hipLaunchKernelGGL(sha512_wide_direct_kernel<8>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
-    else hipLaunchKernelGGL(sha512_wide_kernel, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
+#if defined(SNAPHASH_EXPERIMENT_WIDE_DIRECT)
+    static const int form = [] { const char* e = getenv("SNAPHASH_WIDE_FORM"); return e ? atoi(e) : 0; }();
+    if (form == 1) { hipLaunchKernelGGL(sha512_wide_direct_kernel<5>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests); return hipGetLastError(); }
+    if (form == 2) { hipLaunchKernelGGL(sha512_wide_direct_kernel<6>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests); return hipGetLastError(); }
+    if (form == 3) { hipLaunchKernelGGL(sha512_wide_direct_kernel<8>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests); return hipGetLastError(); }
+#endif
+    hipLaunchKernelGGL(sha512_wide_kernel, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_state, d_digests);
     return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
-// Test-only (CPU): (1) a serial model of deflate_chunks_kernel -- same chunking, hash, greedy parse,
-// token encoder (snappy_amd/csrc/deflate_core.h) and framing -- so that the code tables and the
+// Test-only (CPU): (1) a serial model of deflate_chunks_kernel -- same chunking, hash chains, lazy parse
+// (tests/deflate_model.h), token encoder (snappy_amd/csrc/deflate_core.h) and framing -- so that the code tables and the
 // byte-aligned chunk framing are checked against zlib before the kernel runs on a GPU; (2) the host
 // half of the tar producer (tarpack.cpp): plan + ustar headers + CRC-32.  Not part of the product.
 #include <fcntl.h>
@@ -12,13 +12,14 @@
 #include <vector>
 
 #include "../snappy_amd/csrc/deflate_core.h"
+#include "deflate_model.h"
 #include "../snappy_amd/csrc/tarpack.cpp"
 #include "../snappy_amd/csrc/walk.cpp"
 
 using namespace snaphash;
 
 namespace {
-constexpr uint32_t kChunk = 16384, kHashBits = 11, kGroup = 16;
+constexpr uint32_t kChunk = kDfChunk;
 
 struct BitW {
     std::vector<uint8_t>& o;
@@ -29,85 +30,17 @@ struct BitW {
     void align() { if (n) { o.push_back((uint8_t)acc); acc = 0; n = 0; } }
 };
 
-uint32_t ld32(const uint8_t* p, const uint8_t* end) // like the kernel: bytes past the buffer read as padding
-{
-    uint32_t v = 0;
-    for (int k = 0; k < 4; ++k) if (p + k < end) v |= (uint32_t)p[k] << (8 * k);
-    return v;
-}
+typedef dfmodel::Tok Tok; // len == 0: literal
 
-struct Tok { uint32_t lit, len, dist; }; // len == 0: literal
-
-// The kernel's parse of one chunk: a four-way bucket per hash value (newest first, one 64-bit word), updated
-// in groups of kGroup positions -- every lane of a group reads its bucket before any lane of the group writes, and of
-// the lanes that share a bucket the highest position wins (the kernel's LDS atomic max) -- seeded the same way from
-// the previous chunk; the longest of the up to four candidates (ties: the nearest), greedy with one-byte lazy
-// evaluation, tile (64 positions) by tile.
-void parse_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool has_prev, std::vector<Tok>& toks)
+// piece[0, n_piece): the staging piece the kernel is launched on; [c0, c1) the chunk inside it.  The parse is
+// tests/deflate_model.h (the serial restatement of the kernel's pipeline); the code construction and the block
+// framing below run the kernel's own routines (deflate_core.h).
+void deflate_chunk(const uint8_t* piece, size_t n_piece, size_t c0, size_t c1, std::vector<uint8_t>& out)
 {
-    std::vector<uint64_t> tab(1u << kHashBits, 0);
-    auto hash = [](uint32_t w) { return (w * 0x9E3779B1u) >> (32 - kHashBits); };
-    // entry = position + kChunk + 1 (0 = empty): the previous chunk's positions are 1 .. kChunk
-    auto tile_update = [&](const uint32_t* word, const uint64_t* old, uint32_t first_entry, uint32_t n) {
-        for (uint32_t i = 0; i < n; ++i) {
-            const uint64_t v = ((uint64_t)(first_entry + i) << 48) | (old[i] >> 16);
-            uint64_t& t = tab[hash(word[i])];
-            if (v > t) t = v;
-        }
-    };
-    if (has_prev)
-        for (uint32_t p0 = 0; p0 < kChunk; p0 += 64) {
-            uint32_t word[64];
-            uint64_t old[64];
-            for (uint32_t i = 0; i < 64; ++i) word[i] = ld32(src - kChunk + p0 + i, bufend);
-            for (uint32_t g0 = 0; g0 < 64; g0 += kGroup) {
-                for (uint32_t i = g0; i < g0 + kGroup; ++i) old[i] = tab[hash(word[i])];
-                tile_update(word + g0, old + g0, p0 + g0 + 1, kGroup);
-            }
-        }
-    uint32_t skip_until = 0;
-    for (uint32_t p0 = 0; p0 < len; p0 += 64) {
-        uint32_t mlen[64] = {0}, dist[64] = {0}, word[64] = {0};
-        uint64_t cand[64] = {0};
-        const uint32_t tile_n = len - p0 < 64 ? len - p0 : 64;
-        uint32_t n_can = 0; // positions with four bytes left: a prefix of the tile
-        for (uint32_t i = 0; i < tile_n; ++i) {
-            word[i] = ld32(src + p0 + i, bufend);
-            if (p0 + i + 4 <= len) n_can = i + 1;
-        }
-        for (uint32_t g0 = 0; g0 < n_can; g0 += kGroup) {
-            const uint32_t gn = std::min<uint32_t>(kGroup, n_can - g0);
-            for (uint32_t i = g0; i < g0 + gn; ++i) cand[i] = tab[hash(word[i])];
-            tile_update(word + g0, cand + g0, p0 + g0 + kChunk + 1, gn);
-        }
-        for (uint32_t i = 0; i < n_can; ++i) {
-            const uint32_t pos = p0 + i;
-            const uint32_t maxl = len - pos < 258 ? len - pos : 258;
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t e = (uint32_t)(cand[i] >> (48 - 16 * k)) & 0xffffu;
-                if (!e) break;
-                const int64_t cp = (int64_t)e - 1 - kChunk;
-                uint32_t l = 0;
-                while (l < maxl && src[pos + l] == src[cp + (int64_t)l]) ++l;
-                if (l >= 4 && l > mlen[i]) { mlen[i] = l; dist[i] = (uint32_t)((int64_t)pos - cp); }
-            }
-        }
-        uint32_t rel = skip_until > p0 ? skip_until - p0 : 0;
-        while (rel < tile_n) {
-            if (mlen[rel] >= 4 && rel + 1 < tile_n && mlen[rel + 1] > mlen[rel]) { // lazy: the next byte matches longer
-                toks.push_back(Tok{word[rel] & 0xff, 0, 0}); rel += 1;
-            } else if (mlen[rel] >= 4) { toks.push_back(Tok{0, mlen[rel], dist[rel]}); rel += mlen[rel]; }
-            else { toks.push_back(Tok{word[rel] & 0xff, 0, 0}); rel += 1; }
-        }
-        skip_until = p0 + rel;
-    }
-}
-
-// has_prev: the previous chunk lies in the same staging piece (the kernel seeds its table from it)
-void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool has_prev, std::vector<uint8_t>& out)
-{
+    const uint8_t* src = piece + c0;
+    const uint32_t len = (uint32_t)(c1 - c0);
     std::vector<Tok> toks;
-    parse_chunk(src, len, bufend, has_prev, toks);
+    dfmodel::parse_chunk(piece, n_piece, c0, c1, dfmodel::Params(), toks);
     // symbol counts and the cost of both block kinds
     uint32_t llf[kNumLL] = {0}, df[kNumD] = {0};
     uint64_t extra_bits = 0, fixed_bits = 3 + 7;
@@ -162,11 +95,15 @@ void deflate_chunk(const uint8_t* src, uint32_t len, const uint8_t* bufend, bool
     bw.put(0, 3);  // empty stored block
     bw.align();
     z.push_back(0); z.push_back(0); z.push_back(0xff); z.push_back(0xff);
-    if (z.size() >= len + 5u) {
-        out.push_back(0);
-        out.push_back((uint8_t)len); out.push_back((uint8_t)(len >> 8));
-        out.push_back((uint8_t)~len); out.push_back((uint8_t)(~len >> 8));
-        out.insert(out.end(), src, src + len);
+    if (z.size() >= deflate_stored_size(len)) { // stored: LEN is 16 bits, a full 64 KiB chunk goes out as two blocks of 32 KiB
+        const uint32_t first = len > 65535u ? 32768u : len;
+        for (uint32_t at = 0, n = first; at < len || at == 0; at += n, n = len - at) {
+            out.push_back(0);
+            out.push_back((uint8_t)n); out.push_back((uint8_t)(n >> 8));
+            out.push_back((uint8_t)~n); out.push_back((uint8_t)(~n >> 8));
+            out.insert(out.end(), src + at, src + at + n);
+            if (len == 0) break;
+        }
     } else {
         out.insert(out.end(), z.begin(), z.end());
     }
@@ -180,10 +117,10 @@ extern "C" {
 uint8_t* f3_model_gzip2(const uint8_t* in, size_t n, size_t piece, size_t* out_len)
 {
     std::vector<uint8_t> out(kGzipHeader, kGzipHeader + 10);
-    for (size_t off = 0; off < n; off += kChunk) {
-        const size_t pend = piece ? std::min(n, (off / piece + 1) * piece) : n; // the kernel never reads past its piece (+3)
-        const bool has_prev = piece ? (off % piece) != 0 : off != 0;
-        deflate_chunk(in + off, (uint32_t)(n - off < kChunk ? n - off : kChunk), in + pend, has_prev, out);
+    if (piece == 0) piece = n ? n : 1;
+    for (size_t p0 = 0; p0 < n; p0 += piece) { // the window in front of a chunk never reaches into the previous piece
+        const size_t pn = std::min(piece, n - p0);
+        for (size_t off = 0; off < pn; off += kChunk) deflate_chunk(in + p0, pn, off, std::min(pn, off + kChunk), out);
     }
     out.push_back(0x03); out.push_back(0x00);
     const uint32_t crc = crc32_update(0, in, n);

@@ -381,11 +381,12 @@ __device__ __forceinline__ void token_bits(const ChunkLds& L, bool dynamic, bool
 // One workgroup per chunk.  in: the staged stream (readable up to n_in + 8); slots: nchunks * kDeflateSlot bytes;
 // sizes[c]: bytes chunk c produced; toks: nchunks * kDeflateTokWords words of scratch (the chunk's match tokens).
 __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __restrict__ in, uint64_t n_in, uint8_t* __restrict__ slots,
-                                                              uint32_t* __restrict__ sizes, uint32_t* __restrict__ toks, uint32_t nchunks)
+                                                              uint32_t* __restrict__ sizes, uint32_t* __restrict__ toks, uint32_t chunk0,
+                                                              uint32_t nchunks)
 {
     __shared__ ChunkLds L;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = chunk0 + blockIdx.x;
     if (c >= nchunks) return;
     const uint64_t c0 = (uint64_t)c * kDfChunk;
     const uint32_t len = (uint32_t)((n_in - c0 < kDfChunk) ? (n_in - c0) : kDfChunk);
@@ -617,10 +618,9 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
 // Concatenates the chunk outputs: chunk c's sizes[c] bytes go to out + prefix[c].
 __global__ __launch_bounds__(256) void deflate_compact_kernel(const uint8_t* __restrict__ slots, const uint32_t* __restrict__ sizes,
                                                               const uint64_t* __restrict__ prefix, uint8_t* __restrict__ out,
-                                                              uint32_t nchunks)
+                                                              uint32_t chunk0)
 {
-    const uint32_t c = blockIdx.x;
-    if (c >= nchunks) return;
+    const uint32_t c = chunk0 + blockIdx.x;
     const uint8_t* src = slots + (uint64_t)c * kDeflateSlot;
     uint8_t* dst = out + prefix[c];
     const uint32_t n = sizes[c];
@@ -631,18 +631,18 @@ __global__ __launch_bounds__(256) void deflate_compact_kernel(const uint8_t* __r
 }
 
 hipError_t launch_deflate_chunks(const uint8_t* d_in, uint64_t n_in, uint8_t* d_slots, uint32_t* d_sizes, uint32_t* d_toks,
-                                 uint32_t nchunks, hipStream_t s)
+                                 uint32_t chunk0, uint32_t count, uint32_t nchunks, hipStream_t s)
 {
-    if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(deflate_chunks_kernel, dim3(nchunks), dim3(1024), 0, s, d_in, n_in, d_slots, d_sizes, d_toks, nchunks);
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(deflate_chunks_kernel, dim3(count), dim3(1024), 0, s, d_in, n_in, d_slots, d_sizes, d_toks, chunk0, nchunks);
     return hipGetLastError();
 }
 
 hipError_t launch_deflate_compact(const uint8_t* d_slots, const uint32_t* d_sizes, const uint64_t* d_prefix, uint8_t* d_out,
-                                  uint32_t nchunks, hipStream_t s)
+                                  uint32_t chunk0, uint32_t count, hipStream_t s)
 {
-    if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(deflate_compact_kernel, dim3(nchunks), dim3(256), 0, s, d_slots, d_sizes, d_prefix, d_out, nchunks);
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(deflate_compact_kernel, dim3(count), dim3(256), 0, s, d_slots, d_sizes, d_prefix, d_out, chunk0);
     return hipGetLastError();
 }
 

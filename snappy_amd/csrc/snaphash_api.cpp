@@ -108,6 +108,8 @@ struct DevCtx {
     uint64_t* h_zprefix = nullptr;
     uint8_t* h_zout[2] = {nullptr, nullptr}; // pinned, double-buffered: the consumers read one while the next D2H fills the other
     hipStream_t z_stream = nullptr;          // the compressor's stream
+    hipStream_t z2_stream = nullptr;         // concatenation of a finished piece and its way back to the host
+    std::vector<hipEvent_t> z_ev;            // "the sizes of piece k are on the host"
     size_t z_chunks = 0;
 
     std::vector<EventPair> ev_pool;
@@ -1028,6 +1030,8 @@ static void destroy_dev(DevCtx* c)
     if (c->h_zprefix) (void)hipHostFree(c->h_zprefix);
     for (uint8_t* z : c->h_zout) if (z) (void)hipHostFree(z);
     if (c->z_stream) (void)hipStreamDestroy(c->z_stream);
+    if (c->z2_stream) (void)hipStreamDestroy(c->z2_stream);
+    for (hipEvent_t e : c->z_ev) (void)hipEventDestroy(e);
     for (EventPair& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }

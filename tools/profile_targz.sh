@@ -7,5 +7,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$GRAFT_REPO_ROOT/tools/targz_bench.py" "${2:-text}" "${3:-1024}" > "$OUT/trace.log" 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$GRAFT_REPO_ROOT/tools/targz_bench.py" "${2:-text}" "${3:-1024}" > "$OUT/pmc_fetch.log" 2>&1 || exit 2
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$GRAFT_REPO_ROOT/tools/targz_bench.py" "${2:-text}" "${3:-1024}" > "$OUT/pmc_write.log" 2>&1 || exit 3
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python3 "$GRAFT_REPO_ROOT/tools/targz_bench.py" "${2:-text}" "${3:-1024}" > "$OUT/pmc_sq.log" 2>&1 || exit 4
 find "$OUT" -name "*.csv" -size +8M -delete
 exit 0

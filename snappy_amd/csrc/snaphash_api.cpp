@@ -463,7 +463,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     std::atomic<int> first_err{0};
     std::atomic<int64_t> first_err_src{-1};
     std::vector<ReadOp> ops;
-    const uint64_t S = c->staging;
+    const uint64_t S_full = c->staging;
     unsigned batch = 0;
     double t_wait = 0, t_plan = 0, t_read = 0, t_launch = 0; // where the host side of the engine spends its time (SNAPHASH_TRACE_TREE)
 
@@ -477,6 +477,10 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         // same batch -- a long stream served a fixed slice per batch would still be running, alone, long after the
         // others: the per-stream rate of the kernels is what it is), but at least kMinSegment (a file is opened once per
         // batch it appears in).  Equal streams (config 2) fill a slot kTargetStreams at a time, as before.
+        // The first batches are short (1/8, 1/4, 1/2 of a slot): nothing overlaps the first fill and the first copy, so the
+        // pipeline starts on a small one.  Invisible on a 10 GiB job; a tenth of the time of the 1.3 GiB shard one of
+        // eight ranks gets.
+        const uint64_t S = batch < 3 ? std::max<uint64_t>((S_full >> (3 - batch)) & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20)) : S_full;
         long double total_rem = 0;
         for (uint32_t id : active) total_rem += (long double)(src[id].gpu_len - done[id]);
         const uint64_t floor_q = std::max<uint64_t>(kMinSegment, (S / kTargetStreams) & ~(uint64_t)(kAlign - 1));

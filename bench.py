@@ -469,6 +469,25 @@ def main():
     if force_dist and world == 1 and mode == "full":
         mode = "buffers"
     if mode != "off":
+        # The source buffers belong on the socket this rank's GPU hangs off (first touch by a thread that runs there), as the
+        # engine's staging memory and fill threads are (snaphash_get_engine_info): eight ranks' copies then stay on
+        # their own memory controllers instead of crossing the socket link.
+        numa_note = "not bound"
+        try:
+            probe = Context(device=local_rank, flags=_lib.FLAG_GPU_ONLY)
+            node = probe.engine_info(0)["numa_node"]
+            probe.close()
+            if node >= 0:
+                cpus = []
+                for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+                    lo, _, hi = part.partition("-")
+                    cpus += list(range(int(lo), int(hi or lo) + 1))
+                allowed = sorted(set(cpus) & os.sched_getaffinity(0))
+                if allowed:
+                    os.sched_setaffinity(0, allowed)
+                    numa_note = "rank bound to NUMA node %d (%d CPUs) before its source buffers were allocated" % (node, len(allowed))
+        except Exception as e:  # noqa: BLE001  (placement is an optimisation: never a reason to lose the line)
+            numa_note = "not bound: %r" % (e,)
         host = job["data"].cpu().numpy()  # the same bytes the resident pass hashed, now in this rank's host memory
         del job["data"]
         torch.cuda.empty_cache()
@@ -491,6 +510,7 @@ def main():
         mine = ShardPlan(sizes, world).members(rank)
         local_want = digests[mine] if len(mine) else digests[:0]
         r = e2e_buffers_sharded(ectx, host, job["my_off"], job["my_lens"], local_want, job["total_bytes"], world, fence, allmax, gather)
+        r["source_placement"] = numa_note
         end_to_end["buffers_sharded"] = r
         if world == 1:
             end_to_end["buffers"] = {k: v for k, v in r.items() if k != "per_rank"}  # the name round 2 reported this leg under

@@ -82,7 +82,9 @@ struct DevCtx {
     uint64_t staging = kDefaultStaging;
     uint32_t kernel_pref = SNAPHASH_KERNEL_AUTO;
 
-    Slot slot[2];
+    Slot slot[3]; // [0], [1]: every staging user; [2]: a third buffer for the hashing engine alone, allocated when a call
+                  // has more than two buffers' worth of bytes (fill k+2 then overlaps kernel k: with two, a job whose
+                  // kernels take as long as its copies -- one rank's shard of config 4 -- idles between batches)
     // device-resident entry point
     Job* h_jobs = nullptr; // pinned
     Job* d_jobs = nullptr;
@@ -258,9 +260,10 @@ hipError_t host_alloc(DevCtx* c, void** p, size_t bytes)
     return hipHostMalloc(p, bytes, hipHostMallocDefault);
 }
 
-int ensure_slots(DevCtx* c)
+int ensure_slots(DevCtx* c, int nslots = 2)
 {
-    for (Slot& s : c->slot) {
+    for (int k = 0; k < nslots; ++k) {
+        Slot& s = c->slot[k];
         if (!s.h_buf) {
             HIP_TRY(c, host_alloc(c, (void**)&s.h_buf, c->staging));
             if (c->staging_node < 0) { s.h_buf[0] = 0; c->staging_node = numa_node_of_address(s.h_buf); }
@@ -448,7 +451,10 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     if (err_src) *err_src = -1;
     if (n == 0) return SNAPHASH_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_slots(c);
+    uint64_t job_bytes = 0;
+    for (const Source& sc : src) job_bytes += sc.gpu_len;
+    const unsigned nslots = job_bytes > 2 * c->staging ? 3u : 2u;
+    int rc = ensure_slots(c, (int)nslots);
     if (rc) return rc;
     rc = ensure_state(c, n, true);
     if (rc) return rc;
@@ -468,7 +474,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     double t_wait = 0, t_plan = 0, t_read = 0, t_launch = 0; // where the host side of the engine spends its time (SNAPHASH_TRACE_TREE)
 
     while (!active.empty()) {
-        Slot& sl = c->slot[batch & 1];
+        Slot& sl = c->slot[batch % nslots];
         const double tb0 = now_ms();
         if (sl.busy) { HIP_TRY(c, hipEventSynchronize(sl.done)); sl.busy = false; }
         const double tb1 = now_ms();
@@ -545,7 +551,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     if (getenv("SNAPHASH_TRACE_TREE"))
         fprintf(stderr, "snaphash engine %d: %u batches; waiting for a slot %.1f ms, planning %.1f ms, reads %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
                 c->index, batch, t_wait, t_plan, t_read, t_launch, now_ms() - ts0);
-    c->slot[0].busy = c->slot[1].busy = false;
+    for (Slot& sl : c->slot) sl.busy = false;
     if (rc) return rc;
     if (first_err.load()) {
         const int64_t s = first_err_src.load();

@@ -495,16 +495,18 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
     HuffScratch& S = L.em.hs;
     if (threadIdx.x == 0u) {
         L.freq[256] += 1u; // end of block
-        if (L.freq[288] == 0u) L.freq[288] = 1u; // at least two distance codes, as zlib sends
-        if (L.freq[289] == 0u) L.freq[289] = 1u;
+        const bool ghost0 = L.freq[288] == 0u, ghost1 = L.freq[289] == 0u;
+        if (ghost0) L.freq[288] = 1u; // at least two distance codes, as zlib sends
+        if (ghost1) L.freq[289] = 1u;
         huff_lengths(L.freq, kNumLL, (uint32_t)kMaxBits, L.len, S.w, S.parent, S.order, S.cnt);
         huff_lengths(L.freq + 288, kNumD, (uint32_t)kMaxBits, L.len + 288, S.w, S.parent, S.order, S.cnt);
         build_dyn_header(L.len, L.len + 288, S.rle, S.clfreq, S.cllen, S.clcode, S.w, S.parent, S.order, S.cnt, S.hdr);
         uint32_t db = S.hdr.bits + L.extra_bits;
         for (uint32_t k = 0; k < 318u; ++k)
             if (k < (uint32_t)kNumLL || k >= 288u) db += L.freq[k] * (uint32_t)L.len[k];
-        L.dyn_bits = db;
-        L.use_dynamic = db < L.fixed_bits + L.extra_bits ? 1u : 0u;
+        L.use_dynamic = db < L.fixed_bits + L.extra_bits ? 1u : 0u; // (priced with the two codes that may never be sent, as the model does)
+        // what the block will really take: a distance code that exists only to complete the code is never emitted
+        L.dyn_bits = db - (ghost0 ? (uint32_t)L.len[288] : 0u) - (ghost1 ? (uint32_t)L.len[289] : 0u);
     }
     __syncthreads();
 #if defined(SNAPHASH_DEFLATE_STAMPS)

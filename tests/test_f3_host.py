@@ -41,7 +41,11 @@ def sample_inputs():
     text = (b"The quick brown fox jumps over the lazy dog. " * 3000)
     words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(500)]
     prose = b" ".join(words[int(i)] for i in rng.integers(0, 500, size=40000))
+    # 1 920 bytes on which the dynamic block is ONE byte smaller than the stored one: the price of the block has to leave
+    # out the distance codes that exist only to complete the code (found by tools/soak_deflate.py, round 3)
+    margin = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deflate_margin_1920.bin"), "rb").read()
     return {
+        "stored-or-not margin": margin,
         "empty": b"", "one": b"x", "three": b"abc", "four": b"abcd", "zeros": bytes(100000), "ff": b"\xff" * 70000,
         "random": rng.integers(0, 256, size=50000, dtype=np.uint8).tobytes(), "text": text, "prose": prose,
         "random 64K": rng.integers(0, 256, size=65536, dtype=np.uint8).tobytes(), "random 200000": rng.integers(0, 256, size=200000, dtype=np.uint8).tobytes(),

@@ -146,8 +146,9 @@ int snaphash_abi_version(void);
 /* ---- the primitive: helpers.Sha512sum, batched ----------------------------- */
 
 /* Replaces n calls of helpers.Sha512sum(path) (helpers.go:188).  The library
- * opens and reads the files itself (pread into pinned staging, double-buffered
- * H2D, chunked for files larger than the staging buffer).  digests: n*64 bytes.
+ * opens and reads the files itself (pread into pinned staging -- two buffers, a
+ * third for jobs of more than two -- H2D overlapped with the fill of the next,
+ * chunked for files larger than a staging buffer).  digests: n*64 bytes.
  * status (may be NULL): per file 0 or the errno of the failed open/read. */
 int snaphash_sha512_files(snaphash_ctx *ctx, const char *const *paths, size_t n,
                           uint8_t *digests, int32_t *status);

@@ -87,7 +87,10 @@ namespace snaphash {
 // ---- the parse (round 3: hash chains, one workgroup per chunk) -- shared by the kernel and its CPU model ---------
 // A chunk is one DEFLATE block; inside it every position's candidates come from hash chains over the chunk and the
 // kDfMaxDist bytes in front of it (3-byte hash, 16-bit distance links in a ring), the chain is walked at most
-// kDfDepth links starting at the position's own link, and the parse is greedy with one-byte lazy evaluation.
+// kDfDepth links starting at the position's own link.  The parse then picks, segment by segment (kDfSeg positions),
+// the cheapest way through the segment that those matches allow (a shortest path over the positions: a literal, or
+// the first L bytes of the position's match for every L from 3 to 62), at prices taken from the symbol counts of the
+// chunk so far -- see "the price parse" below.
 constexpr uint32_t kDfChunk = 65536;    // input bytes per chunk (one workgroup, one DEFLATE block)
 constexpr uint32_t kDfSeg = 1920;       // positions indexed / searched / parsed per pipeline step: 30 tiles, two for each of 15 searching waves
 constexpr uint32_t kDfRing = 32768;     // entries of the link ring (>= kDfMaxDist + kDfSeg)
@@ -104,6 +107,36 @@ constexpr uint32_t kDfGood = SNAPHASH_DF_GOOD;   // a match this long cuts what 
 constexpr uint32_t kDfNice = 128;       // a match this long ends the walk
 static_assert(kDfRing >= kDfMaxDist + kDfSeg, "a segment is indexed whole before it is searched");
 static_assert(kDfMaxDist % kDfSeg == 0 && kDfSeg % 64 == 0 && kDfSeg % 16 == 0, "whole window segments, whole tiles (a chunk's last segment may be short)");
+
+// ---- the price parse ---------------------------------------------------------------------------------------------
+// Prices are in quarter bits.  Before a chunk has kDfPriceWarm tokens they are fixed (literal 6 bits, length symbol 7,
+// distance symbol 5); afterwards a symbol seen f times among n costs log2(n + 1) - log2(f + 1), log2 linear between
+// the powers of two, at least one bit and at most 14 (12 for a distance symbol).  Extra bits cost what they are.
+// A match of kDfLongMatch bytes or more is not weighed: the path goes through its position and takes all of it.
+// Among equally cheap ways to a position the longest last token wins.  A segment is parsed as kDfParseWaves windows,
+// one wave each, all at the segment's prices: no token leaves its window.
+constexpr uint32_t kDfParseWaves = 4;
+// where window w of a segment begins, in tiles of 64 positions (8 + 8 + 7 + 7 tiles; a short last segment ends them early)
+DF_HD uint32_t df_window_begin(uint32_t w) { return w < 2u ? w * 512u : (w == 2u ? 1024u : (w == 3u ? 1472u : kDfSeg)); }
+static_assert(kDfSeg == 1920, "the windows above are cut for this segment");
+constexpr uint32_t kDfPriceUnit = 4;
+constexpr uint32_t kDfPriceWarm = 64;
+constexpr uint32_t kDfLongMatch = 63;
+constexpr uint32_t kDfLitPrice0 = 6 * kDfPriceUnit, kDfLenPrice0 = 7 * kDfPriceUnit, kDfDistPrice0 = 5 * kDfPriceUnit;
+constexpr uint32_t kDfLLCap = 14 * kDfPriceUnit, kDfDistCap = 12 * kDfPriceUnit;
+DF_HD uint32_t df_ilog(uint32_t x) // x >= 1
+{
+    const uint32_t e = floor_log2(x);
+    const uint32_t frac = e >= 2u ? (x >> (e - 2u)) & 3u : (x << (2u - e)) & 3u;
+    return e * 4u + frac;
+}
+DF_HD uint32_t df_price(uint32_t f, uint32_t log_total, uint32_t cap)
+{
+    const uint32_t p = log_total - df_ilog(f + 1u); // f <= total: never negative
+    return p < kDfPriceUnit ? kDfPriceUnit : (p > cap ? cap : p);
+}
+// the key of a way to a position: its price, and in the low byte 255 - the length of its last token (1 = a literal)
+DF_HD uint32_t df_key(uint32_t price, uint32_t last) { return (price << 8) | (255u - last); }
 
 // bytes a chunk of len input bytes takes as stored blocks: LEN is a 16-bit field, so a full 64 KiB chunk is two blocks
 DF_HD uint32_t deflate_stored_size(uint32_t len) { return len + (len > 65535u ? 10u : 5u); }

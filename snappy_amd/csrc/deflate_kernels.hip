@@ -18,8 +18,11 @@
 //   search    every position of the segment walks its chain (its own link first, so it only ever sees older
 //             positions) up to kDfDepth candidates within the last 28 800 bytes, four links at a time, and leaves
 //             (length, distance, its byte) in an LDS result word;
-//   parse     wave 0, one segment behind: greedy with one-byte lazy evaluation -- the lanes say where a match
-//             exists and where the next byte matches longer, a scalar loop walks from token to token -> bitmaps;
+//   parse     wave 0, one segment behind: the price parse of deflate_core.h -- the cheapest way through the segment
+//             at prices from the chunk's symbol counts so far.  A shortest path, forward: the ways to the next 64
+//             positions live in ONE register, a lane each; a step offers the position's literal and every length of
+//             its match to them in one masked v_min and shifts the register by a lane (DPP); the way back hops
+//             from token to token through a byte per position -> bitmaps, and the chosen lengths into the results;
 //   finish    one more segment behind: symbol counts (LDS atomics), match tokens to an HBM scratch (4 B per
 //             MATCH, not per byte), the two block prices.  Search tiles and finish tiles come from one queue.
 // Then one lane builds the dynamic Huffman codes and the block header (deflate_core.h: the CPU model runs the very
@@ -110,6 +113,12 @@ struct ChunkLds {
     uint32_t freq[320];   // literal/length symbols 0..285, distance symbols at 288..317; after the codes are built: code << 8 | length
     uint8_t len[320];
     unsigned long long lastmask[kSegTiles]; // indexing: the lanes of each tile that are the last of their hash in it
+    uint8_t from8[kDfSeg + 64];  // the parse: length of the last token of the cheapest way to each position of the segment
+    uint8_t price_ll[288];       // the parse: prices (quarter bits) of the literal/length symbols, of the distance symbols
+    uint8_t price_d[32];
+    uint32_t across_done;  // tiles of the step's segment whose links are complete (the searchers of a tile wait for it)
+    uint32_t finish_done;  // tiles of segment j - 2 whose tokens are counted (the parse waits for all: its prices)
+    uint32_t ntok, nmatch; // the parse: tokens / matches of the segments whose tokens are counted (token_counts)
     uint32_t queue[2];    // work items handed out in the current step (the other counter is reset for the next one)
     uint32_t fixed_bits, extra_bits, total_bits, dyn_bits, use_dynamic;
 };
@@ -213,6 +222,7 @@ __device__ __forceinline__ void index_segment_across(ChunkLds& L, uint64_t n_in,
             L.ix.ring[p_pos & kRingMask] = (uint16_t)d;
         }
         if (p_last) L.ix.head[p_h] = p_rel1;
+        if (t >= 1u && lane == 0u) __hip_atomic_store(&L.across_done, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); // tiles < t are linked
         // this tile's head reads: behind the previous tile's head writes (one wave's LDS operations keep their order)
         uint32_t q1 = 0;
         if (need) q1 = L.ix.head[h];
@@ -281,51 +291,173 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     return best >= kDfMinMatch ? res_pack(best, bdist, byte) : res_pack(0u, 0u, byte);
 }
 
-// ---- parser (wave 0): which positions of a segment begin a token, which of those are matches ----------------------
-// Greedy with one-byte lazy evaluation, tile by tile: the lanes say in parallel where a match exists and where the
-// next byte matches longer; the walk from token to token is a scalar loop.  skip_until: first chunk-relative position
-// not covered by an earlier match; nmatch: matches so far.
-__device__ __forceinline__ void parse_segment(ChunkLds& L, const uint32_t* __restrict__ res, uint32_t seg_rel0, uint32_t len, uint32_t lane,
-                                              uint32_t& skip_until, uint32_t& nmatch)
+// ---- parser (wave 0): the price parse of one segment (deflate_core.h; tests/deflate_model.h is its serial form) -------
+// In: the search results of the segment.  Out: startbits / matchbits / match_base of its tiles, and in the result word
+// of every position that begins a match the length the parse chose (it may be shorter than the one found).
+// ntok / nmatch: tokens / matches of the chunk's earlier segments (L.freq holds exactly their symbols).
+// One step of the parse's window: w = min(w, cand) in lanes offset .. offset + size - 1 (uniform; the size is the low
+// six bits of `size`: s_bfm_b64 builds the mask straight into EXEC), then every lane takes its upper neighbour's value
+// (wave_shl:1; lane 63 keeps its own).  Only where the whole wave is active: EXEC is all ones behind it.  (The s_nop:
+// a DPP operation reads a VGPR no sooner than two wait states after a VALU wrote it.)
+__device__ __forceinline__ uint32_t min_and_shift(uint32_t w, uint32_t cand, uint32_t size, uint32_t offset)
 {
-    uint32_t r_next = res[lane]; // the next tile's result words are on their way while this tile is walked
-    for (uint32_t t = 0; t < kSegTiles; ++t) {
-        const uint32_t p0 = seg_rel0 + t * 64u;
-        if (p0 >= len) break;
-        const uint32_t tile = p0 >> 6;
-        const uint32_t mlen = r_next & 0x1ffu;
-        if (t + 1u < kSegTiles) r_next = res[(t + 1u) * 64u + lane];
-        const uint32_t tile_n = (len - p0 < 64u) ? len - p0 : 64u;
-        // lane i+1's length: wave_shl:1 (DPP, no LDS traffic); lane 63 reads 0
-        const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlen, 0x130, 0xf, 0xf, false);
-        const bool has = mlen >= kDfMinMatch && lane < tile_n;
-        const bool lazy = has && lane + 1u < tile_n && next > mlen; // the next byte matches longer: this one goes out as a literal
-        const uint64_t mm_all = __ballot(has);
-        const uint64_t take = __ballot(has && !lazy);                // a token that starts here is a match
-        const uint32_t step = (has && !lazy) ? mlen : 1u;            // where the token that starts here ends
-        const uint64_t inside = (tile_n == 64u) ? ~0ull : ((1ull << tile_n) - 1ull);
-        uint64_t start_mask = 0;
-        uint32_t rel = (skip_until > p0) ? skip_until - p0 : 0u;
-        while (rel < tile_n) { // from token to token; runs of literals in one stride
-            const uint64_t mm = mm_all & (~0ull << rel);
-            if (mm == 0ull) {
-                start_mask |= (~0ull << rel) & inside;
-                rel = tile_n;
+    asm volatile("s_bfm_b64 exec, %2, %3\n\tv_min_u32 %0, %0, %1\n\ts_mov_b64 exec, -1\n\ts_nop 0\n\t"
+                 "v_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(w) : "v"(cand), "s"(size), "s"(offset));
+    return w;
+}
+// v_writelane_b32: lane `lane` (uniform) of v <- the uniform value.  One SGPR per VALU operation on gfx9: a lane that
+// is not a constant goes through M0 (nothing else in this kernel uses it).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t value, uint32_t lane)
+{
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(lane) : "m0");
+    return v;
+}
+#pragma clang diagnostic pop
+
+// One window [wa, wb) of segment [seg_rel0, seg_rel0 + m): every wave that parses writes the same price tables
+// (same inputs, same values: whichever write lands last changes nothing), then works on positions of its own.
+__device__ __forceinline__ void parse_window(ChunkLds& L, uint32_t* res, uint32_t seg_rel0, uint32_t wa, uint32_t wb, uint32_t lane)
+{
+    const uint32_t tile0 = seg_rel0 >> 6;
+    const uint32_t ntok = L.ntok, nmatch = L.nmatch;
+    if (ntok < kDfPriceWarm) {
+        for (uint32_t k = lane; k < 288u; k += 64u) L.price_ll[k] = (uint8_t)(k < 256u ? kDfLitPrice0 : kDfLenPrice0);
+        if (lane < 32u) L.price_d[lane] = (uint8_t)kDfDistPrice0;
+    } else {
+        const uint32_t lt = df_ilog(ntok + 1u), dt = df_ilog(nmatch + 1u);
+        for (uint32_t k = lane; k < 288u; k += 64u) L.price_ll[k] = (uint8_t)df_price(k < (uint32_t)kNumLL ? L.freq[k] : 0u, lt, kDfLLCap);
+        if (lane < 32u) L.price_d[lane] = (uint8_t)(nmatch ? df_price(lane < (uint32_t)kNumD ? L.freq[288u + lane] : 0u, dt, kDfDistCap) : kDfDistPrice0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wa >= wb) return;
+    uint32_t lenkey = 0xffffff00u; // this lane's token length is its number: the price of that length and 255 - it
+    if (lane >= 3u) {
+        uint32_t sy, eb, ev;
+        len_symbol(lane, sy, eb, ev);
+        lenkey = df_key((uint32_t)L.price_ll[sy] + eb * kDfPriceUnit, lane);
+    }
+    const uint32_t tile_end = (wb + 63u) >> 6;
+
+    uint32_t pos = wa;
+    while (pos < wb) { // a run: from pos to the window's end or to the first match of kDfLongMatch or more
+        const uint32_t run0 = pos;
+        uint32_t w = lane == 0u ? 0u : 0xffffffffu; // lane l: the key of the cheapest way found so far to position (current) + l
+        uint32_t lit_key = 0xffffffffu;             // ... except the way through the previous position's literal: that one stays scalar
+        uint32_t end = wb, long_len = 0;
+        for (uint32_t t = pos >> 6; t < tile_end; ++t) {
+            const uint32_t r = res[t * 64u + lane];
+            const uint32_t ml = r & 0x1ffu, dist = (r >> 9) & 0x7fffu, byte = r >> 24;
+            const uint32_t ppos = t * 64u + lane;
+            const uint32_t room = ppos < wb ? wb - ppos : 0u;
+            const uint32_t mlc = ml < room ? ml : room;
+            const uint32_t min_l = dist > kDfTooFar ? 4u : 3u;
+            const uint32_t hi = mlc < kDfLongMatch - 1u ? mlc : kDfLongMatch - 1u;
+            const uint32_t size = hi >= min_l ? hi - min_l + 1u : 0u;
+            uint32_t ds, de, dv;
+            dist_symbol(dist ? dist : 1u, ds, de, dv);
+            const uint32_t dp = (uint32_t)L.price_d[ds] + de * kDfPriceUnit;
+            const uint32_t lp = L.price_ll[byte];
+            const uint32_t info = size | (min_l << 6) | (lp << 9) | (dp << 16);
+            const uint32_t k0 = (t == (pos >> 6)) ? (pos & 63u) : 0u;
+            const uint32_t tile_n = (wb - t * 64u < 64u) ? wb - t * 64u : 64u;
+            const uint64_t fm = __ballot(mlc >= kDfLongMatch && lane >= k0 && lane < tile_n);
+            const uint32_t k1 = fm ? (uint32_t)__builtin_ctzll(fm) : tile_n;
+            uint32_t f = 0;
+            for (uint32_t k = k0; k < k1; ++k) {
+                const uint32_t s_info = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)k);
+                uint32_t s_key = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+                s_key = s_key < lit_key ? s_key : lit_key;
+                f = write_lane(f, s_key, k);
+                const uint32_t cost = s_key >> 8;
+                const uint32_t s_min = (s_info >> 6) & 7u, s_lp = (s_info >> 9) & 127u, s_dp = s_info >> 16;
+                lit_key = ((cost + s_lp) << 8) | 254u;
+                const uint32_t cand = lenkey + ((cost + s_dp) << 8);
+                w = min_and_shift(w, cand, s_info, s_min); // lane 63 keeps its value: no token is longer than 62, so nothing ever lowers it from "no way yet"
+            }
+            if (ppos > run0 && lane < k1) L.from8[ppos] = (uint8_t)(255u - (f & 255u)); // (the run's first position belongs to whoever ended there)
+            if (fm) {
+                end = t * 64u + k1;
+                long_len = (uint32_t)__builtin_amdgcn_readlane((int)mlc, (int)k1);
                 break;
             }
-            const uint32_t f = (uint32_t)__builtin_ctzll(mm);
-            start_mask |= (~0ull << rel) & ((2ull << f) - 1ull); // literals rel .. f-1 and the token at f
-            rel = f + (uint32_t)__builtin_amdgcn_readlane((int)step, (int)f);
         }
-        skip_until = p0 + rel;
-        const uint64_t match_mask = start_mask & take;
-        if (lane == 0u) {
-            L.startbits[tile] = start_mask;
-            L.matchbits[tile] = match_mask;
-            L.match_base[tile] = nmatch;
+        if (lane == 0u && end > run0) L.from8[end] = (uint8_t)(255u - ((w < lit_key ? w : lit_key) & 255u)); // lane 0 is position end now
+        // the way back: from end to run0, a hop per token
+        {
+            uint32_t p = end, from_tile = 0xffffffffu, mask_tile = 0xffffffffu, ft = 0;
+            uint64_t cur = 0;
+            while (p > run0) {
+                const uint32_t tp = p >> 6;
+                if (tp != from_tile) { ft = L.from8[tp * 64u + lane]; from_tile = tp; }
+                p -= (uint32_t)__builtin_amdgcn_readlane((int)ft, (int)(p & 63u));
+                const uint32_t ts = p >> 6;
+                if (ts != mask_tile) {
+                    if (cur != 0ull && lane == 0u) atomicOr(&L.startbits[tile0 + mask_tile], cur);
+                    mask_tile = ts;
+                    cur = 0;
+                }
+                cur |= 1ull << (p & 63u);
+            }
+            if (cur != 0ull && lane == 0u) atomicOr(&L.startbits[tile0 + mask_tile], cur);
         }
-        nmatch += (uint32_t)__builtin_popcountll(match_mask);
+        if (end < wb) { // the long match
+            if (lane == 0u) atomicOr(&L.startbits[tile0 + (end >> 6)], 1ull << (end & 63u));
+            pos = end + long_len;
+        } else {
+            pos = wb;
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // The tokens of the window (its tiles are its own: windows begin at whole tiles).  A token ends where the next
+    // begins or where the window ends: lengths, which tokens are matches, the chosen lengths into the result words.
+    const auto starts_of = [&](uint32_t t) -> uint64_t {
+        uint64_t v = t < tile_end ? L.startbits[tile0 + t] : 0ull;
+        if ((wb >> 6) == t) v |= 1ull << (wb & 63u); // the window's end counts as a start here
+        return v;
+    };
+    uint64_t sm_v = starts_of(wa >> 6);
+    for (uint32_t t = wa >> 6; t < tile_end; ++t) {
+        const uint64_t nx_v = starts_of(t + 1u);
+        const uint32_t r = res[t * 64u + lane];
+        const uint32_t ppos = t * 64u + lane;
+        const bool my_start = ppos < wb && ((sm_v >> lane) & 1ull);
+        const uint32_t room = ppos < wb ? wb - ppos : 0u;
+        const uint32_t ml = r & 0x1ffu;
+        const uint32_t mlc = ml < room ? ml : room;
+        const uint64_t above = lane < 63u ? sm_v >> (lane + 1u) : 0ull;
+        uint32_t tl = above ? (uint32_t)__builtin_ctzll(above) + 1u : (64u - lane) + (nx_v ? (uint32_t)__builtin_ctzll(nx_v) : 0u);
+        if (mlc >= kDfLongMatch) tl = mlc; // a long match was taken whole
+        const bool my_match = my_start && tl >= kDfMinMatch;
+        const uint64_t mk = __ballot(my_match);
+        if (my_match) res[t * 64u + lane] = (r & ~0x1ffu) | tl;
+        const uint64_t real = __ballot(my_start);
+        if (lane == 0u) {
+            L.startbits[tile0 + t] = real;
+            L.matchbits[tile0 + t] = mk;
+            L.match_base[tile0 + t] = (uint32_t)__builtin_popcountll(mk); // a count: token_counts makes it the base
+        }
+        sm_v = nx_v;
+    }
+}
+
+// A step later (wave 0; every window is done): the segment's matches per tile become bases into the token scratch,
+// its tokens and matches join the chunk's counts.
+__device__ __forceinline__ void token_counts(ChunkLds& L, uint32_t seg_rel0, uint32_t m, uint32_t lane)
+{
+    const uint32_t ntile = (m + 63u) >> 6, tile0 = seg_rel0 >> 6;
+    const uint32_t cnt = lane < ntile ? L.match_base[tile0 + lane] : 0u;
+    const uint32_t sts = lane < ntile ? (uint32_t)__builtin_popcountll(L.startbits[tile0 + lane]) : 0u;
+    const uint32_t incl = wave_scan_incl(cnt, lane);
+    const uint32_t nmatch = L.nmatch, ntok = L.ntok;
+    if (lane < ntile) L.match_base[tile0 + lane] = nmatch + incl - cnt;
+    const uint32_t all_m = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), all_t = wave_sum(sts, lane);
+    if (lane == 0u) { L.nmatch = nmatch + all_m; L.ntok = ntok + all_t; }
 }
 
 // ---- finisher: the tokens of one parsed tile -> symbol counts, match tokens to the scratch, block prices -------------
@@ -408,71 +540,87 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
         *reinterpret_cast<uint4*>(L.data + at) = v;
         if (at == 0u) *reinterpret_cast<uint4*>(L.data + kDataRing) = v;
     }
-    if (threadIdx.x == 0u) { L.queue[0] = 0u; L.queue[1] = 0u; }
+    for (uint32_t i = threadIdx.x; i < kChunkTiles; i += kThreads) L.startbits[i] = 0ull; // the parse ORs a tile's starts together
+    if (threadIdx.x == 0u) { L.queue[0] = 0u; L.queue[1] = 0u; L.ntok = 0u; L.nmatch = 0u; }
     __syncthreads();
 
     // ---------------- the pipeline, per step i ----------------
     //   all waves   stage the bytes of segment i (kLook ahead); index it inside its tiles (two tiles per wave)
     //   then        wave 0: the links across tiles | the others: finish segment j - 2 (tiles from a queue)
-    //   then        waves 1-15: search chunk segment j = i - nwin (30 tiles from a queue) | wave 0: parse segment j - 1
-    uint32_t skip_until = 0, nmatch = 0, fixed_lane = 0, extra_lane = 0;
+    //   then        search chunk segment j = i - nwin (30 tiles from a queue); before they join, waves 1-4 parse a
+    //               window (a quarter) of segment j - 1 each.  Wave 0 turns that parse into tokens at the top of the
+    //               next step (token_counts), in front of the barriers the finishers wait behind.
+    uint32_t fixed_lane = 0, extra_lane = 0;
     const uint32_t steps = nwin + nseg + 2u;
 #if defined(SNAPHASH_DEFLATE_STAMPS)
-    uint64_t t_ins = 0, t_par = 0, t_sea = 0, t_fin = 0, t_all0 = __builtin_amdgcn_s_memtime();
+    uint64_t t_ins = 0, t_par = 0, t_sea = 0, t_fin = 0, t_wait = 0, t_all0 = __builtin_amdgcn_s_memtime();
 #define STAMP(acc, code) { const uint64_t s_ = __builtin_amdgcn_s_memtime(); code; acc += __builtin_amdgcn_s_memtime() - s_; }
+    uint64_t t_bar[5] = {0, 0, 0, 0, 0};
+#define SYNC_STAMPED(n) { const uint64_t s_ = __builtin_amdgcn_s_memtime(); __syncthreads(); if (chunk_step) t_bar[n] += __builtin_amdgcn_s_memtime() - s_; }
 #else
 #define STAMP(acc, code) { code; }
+#define SYNC_STAMPED(n) __syncthreads()
 #endif
     for (uint32_t i = 0; i < steps; ++i) {
         const bool chunk_step = i >= nwin;
         const uint32_t j = i - nwin; // the chunk segment this step indexes and searches (meaningful when chunk_step)
         const bool do_finish = chunk_step && j >= 2u && j - 2u < nseg;
-        if (i < nwin + nseg) {
+        const uint32_t fin_rel0 = (j - 2u) * kDfSeg; // (meaningful when do_finish)
+        const uint32_t fin_m = do_finish ? ((len - fin_rel0 < kDfSeg) ? len - fin_rel0 : kDfSeg) : 0u;
+        if (do_finish && wave == 0u) STAMP(t_par, token_counts(L, fin_rel0, fin_m, lane));
+        if (threadIdx.x == 0u) { L.across_done = 0u; L.finish_done = 0u; }
+        const bool do_index = i < nwin + nseg;
+        if (do_index) {
             const uint64_t seg0 = s0 + (uint64_t)i * kDfSeg;
             stage_bytes(L, in, n_in, seg0 + kLook, threadIdx.x);
-            __syncthreads();
+            SYNC_STAMPED(0);
             // the result buffer this step's search will fill is free until then: the owners' signatures live there
             uint8_t* owner = reinterpret_cast<uint8_t*>(L.res[(chunk_step ? j : i) % 3u]);
             static_assert(sizeof(L.res[0]) >= kHeadN, "the signatures of one segment fit a result buffer");
             STAMP(t_ins, for (uint32_t t = wave; t < kSegTiles; t += kWaves) index_tile_inside(L, owner, n_in, seg0, t, c1, lane));
-            __syncthreads();
-            if (wave == 0u) {
-                __builtin_amdgcn_s_setprio(3);
-                STAMP(t_ins, index_segment_across(L, n_in, s0, seg0, c1, lane));
-                __builtin_amdgcn_s_setprio(0);
-            }
         }
-        // meanwhile (and in the draining steps): the tokens of segment j - 2
-        if (do_finish) {
+        SYNC_STAMPED(1);
+        // From here to the step's last barrier nothing waits for everybody: the links across tiles announce their
+        // progress tile by tile (a searcher waits for its own tile), the finishers count their tiles (the parse waits
+        // for the last: its prices are the counts).
+        if (do_index && wave == 0u) {
+            const uint64_t seg0 = s0 + (uint64_t)i * kDfSeg;
+            __builtin_amdgcn_s_setprio(3);
+            STAMP(t_ins, index_segment_across(L, n_in, s0, seg0, c1, lane));
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (do_finish) { // the tokens of segment j - 2
             for (;;) {
                 uint32_t item = 0;
                 if (lane == 0u) item = atomicAdd(&L.queue[0], 1u);
                 item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
-                if (item >= kSegTiles) break;
-                const uint32_t rel0 = (j - 2u) * kDfSeg + item * 64u;
-                if (rel0 < len) STAMP(t_fin, finish_tile(L, L.res[(j - 2u) % 3u], item, rel0 >> 6, lane, fixed_lane, extra_lane, tok));
+                if (item * 64u >= fin_m) break;
+                STAMP(t_fin, finish_tile(L, L.res[(j - 2u) % 3u], item, (fin_rel0 >> 6) + item, lane, fixed_lane, extra_lane, tok));
+                if (lane == 0u) __hip_atomic_fetch_add(&L.finish_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        __syncthreads();
-        if (!chunk_step) continue; // the window in front of the chunk is only indexed
-        if (wave == 0u) { // the one serial job of the step; the fifteen others search two tiles each meanwhile
-            if (j >= 1u && j - 1u < nseg) {
-                __builtin_amdgcn_s_setprio(3);
-                STAMP(t_par, parse_segment(L, L.res[(j - 1u) % 3u], (j - 1u) * kDfSeg, len, lane, skip_until, nmatch));
-                __builtin_amdgcn_s_setprio(0);
-            }
-        } else if (j < nseg) {
+        if (chunk_step && wave >= 1u && wave <= kDfParseWaves && j >= 1u && j - 1u < nseg) { // a window of segment j - 1 (wave 0 has the step's other serial job)
+            const uint32_t rel0 = (j - 1u) * kDfSeg;
+            const uint32_t m = (len - rel0 < kDfSeg) ? len - rel0 : kDfSeg;
+            const uint32_t wa = df_window_begin(wave - 1u), wb = df_window_begin(wave) < m ? df_window_begin(wave) : m;
+            const uint32_t fin_tiles = (fin_m + 63u) >> 6;
+            STAMP(t_wait, while (__hip_atomic_load(&L.finish_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < fin_tiles) __builtin_amdgcn_s_sleep(1));
+            __builtin_amdgcn_s_setprio(3);
+            STAMP(t_par, parse_window(L, L.res[(j - 1u) % 3u], rel0, wa < m ? wa : m, wb, lane));
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (chunk_step && j < nseg) {
             for (;;) {
                 uint32_t item = 0;
                 if (lane == 0u) item = atomicAdd(&L.queue[1], 1u);
                 item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
                 if (item >= kSegTiles) break;
+                STAMP(t_wait, while (__hip_atomic_load(&L.across_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= item) __builtin_amdgcn_s_sleep(1));
                 STAMP(t_sea, L.res[j % 3u][item * 64u + lane] = search_position(L, in, n_in, c0 + (uint64_t)j * kDfSeg + item * 64u + lane, c1));
             }
         }
-        if (threadIdx.x == 0u) L.queue[0] = 0u; // the finish queue: handed out again only behind the next barriers
-        __syncthreads();
-        if (threadIdx.x == 0u) L.queue[1] = 0u; // the search queue: likewise
+        SYNC_STAMPED(3);
+        if (threadIdx.x == 0u) { L.queue[0] = 0u; L.queue[1] = 0u; } // handed out again only behind the next step's barriers
     }
     // the block prices: every wave holds a share
     {
@@ -483,9 +631,9 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
     }
 #if defined(SNAPHASH_DEFLATE_STAMPS)
     const uint64_t t_pipe = __builtin_amdgcn_s_memtime() - t_all0;
-    if (c == 37u && lane == 0u && wave <= 1u)
-        printf("chunk %u wave %u: pipeline %llu cycles; insert %llu parse %llu search %llu finish %llu\n", c, wave, (unsigned long long)t_pipe,
-               (unsigned long long)t_ins, (unsigned long long)t_par, (unsigned long long)t_sea, (unsigned long long)t_fin);
+    if (c == 37u && lane == 0u && (wave <= 1u || wave == 5u))
+        printf("chunk %u wave %u: pipeline %llu cycles; insert %llu parse %llu search %llu finish %llu spinning %llu; waiting at the step's barriers %llu %llu %llu %llu\n", c, wave, (unsigned long long)t_pipe,
+               (unsigned long long)t_ins, (unsigned long long)t_par, (unsigned long long)t_sea, (unsigned long long)t_fin, (unsigned long long)t_wait, (unsigned long long)t_bar[0], (unsigned long long)t_bar[1], (unsigned long long)t_bar[2], (unsigned long long)t_bar[3]);
     const uint64_t t_tail0 = __builtin_amdgcn_s_memtime();
 #endif
     __threadfence_block(); // the match tokens in the scratch are read back by every wave of this workgroup

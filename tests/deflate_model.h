@@ -7,7 +7,10 @@
 //            if it agrees with p in the four bytes ending at the current best length (it cannot be longer otherwise);
 //            longer wins, the first found keeps ties; nice ends the walk, good cuts the links left to a quarter;
 //            a 3-byte match farther than too_far is dropped
-//   parse    greedy with one-byte lazy evaluation, tile (64 positions) by tile: no look-ahead across a tile's end
+//   parse    the price parse of deflate_core.h, segment (1 920 positions) by segment, window (512 or 448) by window: forward,
+//            every position offering a literal and the first L bytes of its match (L from 3, or 4 for a distance
+//            beyond too_far, to 62) to the positions behind it; a match of 63 or more ends the run: the way to its
+//            position is traced back, the match is taken whole, and a new run starts behind it
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -84,18 +87,66 @@ inline void parse_chunk(const uint8_t* in, size_t n_in, size_t c0, size_t c1, co
         }
         if (st) { st->tile_max_steps += tile_max; st->tiles++; }
     }
-    size_t rel = 0;
-    while (rel < len) {
-        const size_t tile_end = std::min(len, (rel / 64 + 1) * 64);
-        if (mlen[rel] >= snaphash::kDfMinMatch && rel + 1 < tile_end && mlen[rel + 1] > mlen[rel]) { // lazy: the next byte matches longer
-            toks.push_back(Tok{in[c0 + rel], 0, 0});
-            rel += 1;
-        } else if (mlen[rel] >= snaphash::kDfMinMatch) {
-            toks.push_back(Tok{0, mlen[rel], mdist[rel]});
-            rel += mlen[rel];
+    // the price parse
+    uint32_t f_ll[snaphash::kNumLL] = {0}, f_d[snaphash::kNumD] = {0}, ntok = 0, nmatch = 0;
+    uint32_t lit_price[256], len_price[snaphash::kDfLongMatch], dsym_price[snaphash::kNumD];
+    std::vector<uint32_t> key(snaphash::kDfSeg + 1);
+    std::vector<uint32_t> tok_len(snaphash::kDfSeg);
+    for (size_t g0 = 0; g0 < len; g0 += snaphash::kDfSeg) {
+        const uint32_t m = (uint32_t)std::min<size_t>(snaphash::kDfSeg, len - g0);
+        using namespace snaphash;
+        if (ntok < kDfPriceWarm) {
+            for (uint32_t b = 0; b < 256u; ++b) lit_price[b] = kDfLitPrice0;
+            for (uint32_t L = 3; L < kDfLongMatch; ++L) { uint32_t sy, eb, ev; len_symbol(L, sy, eb, ev); len_price[L] = kDfLenPrice0 + eb * kDfPriceUnit; }
+            for (uint32_t d = 0; d < (uint32_t)kNumD; ++d) dsym_price[d] = kDfDistPrice0;
         } else {
-            toks.push_back(Tok{in[c0 + rel], 0, 0});
-            rel += 1;
+            const uint32_t lt = df_ilog(ntok + 1u);
+            for (uint32_t b = 0; b < 256u; ++b) lit_price[b] = df_price(f_ll[b], lt, kDfLLCap);
+            for (uint32_t L = 3; L < kDfLongMatch; ++L) { uint32_t sy, eb, ev; len_symbol(L, sy, eb, ev); len_price[L] = df_price(f_ll[sy], lt, kDfLLCap) + eb * kDfPriceUnit; }
+            const uint32_t dt = df_ilog(nmatch + 1u);
+            for (uint32_t d = 0; d < (uint32_t)kNumD; ++d) dsym_price[d] = nmatch ? df_price(f_d[d], dt, kDfDistCap) : kDfDistPrice0;
+        }
+        std::fill(tok_len.begin(), tok_len.end(), 0u); // tok_len[i] != 0: a token of that length starts at i
+        for (uint32_t wi = 0; wi < kDfParseWaves && df_window_begin(wi) < m; ++wi) { // the windows of the segment: no token leaves its own
+        const uint32_t wa = df_window_begin(wi), wb = std::min(m, df_window_begin(wi + 1u));
+        uint32_t pos = wa;
+        while (pos < wb) {
+            const uint32_t run0 = pos;
+            std::fill(key.begin(), key.end(), 0xffffffffu);
+            key[run0] = 0;
+            uint32_t i = run0;
+            for (; i < wb; ++i) {
+                const uint32_t mlc = std::min(mlen[g0 + i], wb - i);
+                if (mlc >= kDfLongMatch) break;
+                const uint32_t c = key[i] >> 8;
+                key[i + 1] = std::min(key[i + 1], df_key(c + lit_price[in[c0 + g0 + i]], 1u));
+                if (mlc < kDfMinMatch) continue;
+                uint32_t ds, de, dv;
+                dist_symbol(mdist[g0 + i], ds, de, dv);
+                const uint32_t dp = dsym_price[ds] + de * kDfPriceUnit;
+                for (uint32_t L = mdist[g0 + i] > P.too_far ? 4u : 3u; L <= std::min(mlc, kDfLongMatch - 1u); ++L)
+                    key[i + L] = std::min(key[i + L], df_key(c + len_price[L] + dp, L));
+            }
+            for (uint32_t p = i; p > run0;) { // the way back
+                const uint32_t L = 255u - (key[p] & 255u);
+                p -= L;
+                tok_len[p] = L;
+            }
+            if (i < wb) { tok_len[i] = std::min(mlen[g0 + i], wb - i); pos = i + tok_len[i]; }
+            else pos = wb;
+        }
+        }
+        for (uint32_t i = 0; i < m;) {
+            const uint32_t L = tok_len[i];
+            if (L == 1u) { toks.push_back(Tok{in[c0 + g0 + i], 0, 0}); f_ll[in[c0 + g0 + i]]++; }
+            else {
+                toks.push_back(Tok{0, L, mdist[g0 + i]});
+                uint32_t sy, eb, ev, ds, de, dv;
+                len_symbol(L, sy, eb, ev); dist_symbol(mdist[g0 + i], ds, de, dv);
+                f_ll[sy]++; f_d[ds]++; nmatch++;
+            }
+            ntok++;
+            i += L;
         }
     }
 }

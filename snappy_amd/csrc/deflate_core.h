@@ -283,8 +283,7 @@ DF_HD uint32_t cl_order(uint32_t i) // RFC 1951 sec. 3.2.7: the order in which t
 // builds the code length code.  tok[i] = symbol | extra value << 8.  clfreq/cl_len/cl_code: kNumCL entries.
 // Scratch as huff_lengths (for n = kNumCL).
 template <typename U32P, typename U16P>
-DF_HD_CALL void build_dyn_header(const uint8_t* ll_len, const uint8_t* d_len, U16P tok, U32P clfreq, uint8_t* cl_len, U32P cl_code,
-                                 U32P w, U16P parent, U16P order, U32P cnt, DynHeader& h)
+DF_HD_CALL void dyn_header_tokens(const uint8_t* ll_len, const uint8_t* d_len, U16P tok, U32P clfreq, DynHeader& h)
 {
     uint32_t nll = kNumLL, nd = kNumD;
     while (nll > 257u && ll_len[nll - 1u] == 0) --nll;
@@ -310,16 +309,26 @@ DF_HD_CALL void build_dyn_header(const uint8_t* ll_len, const uint8_t* d_len, U1
     uint32_t used = 0;
     for (int k = 0; k < kNumCL; ++k) used += clfreq[k] != 0;
     if (used < 2u) { if (clfreq[0] == 0) clfreq[0] = 1; else clfreq[1] = 1; }
+    h.nll = nll; h.nd = nd; h.ntok = nt;
+}
+// bits one run-length token takes behind its code
+DF_HD uint32_t cl_extra_bits(uint32_t sym) { return sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u; }
+
+template <typename U32P, typename U16P>
+DF_HD_CALL void build_dyn_header(const uint8_t* ll_len, const uint8_t* d_len, U16P tok, U32P clfreq, uint8_t* cl_len, U32P cl_code,
+                                 U32P w, U16P parent, U16P order, U32P cnt, DynHeader& h)
+{
+    dyn_header_tokens(ll_len, d_len, tok, clfreq, h);
     huff_lengths(clfreq, kNumCL, (uint32_t)kMaxCLBits, cl_len, w, parent, order, cnt);
     huff_codes(cl_len, kNumCL, cl_code, cnt);
     uint32_t ncl = kNumCL;
     while (ncl > 4u && cl_len[cl_order(ncl - 1u)] == 0) --ncl;
     uint32_t bits = 3u + 5u + 5u + 4u + 3u * ncl;
-    for (uint32_t t = 0; t < nt; ++t) {
+    for (uint32_t t = 0; t < h.ntok; ++t) {
         const uint32_t sym = tok[t] & 0xffu;
-        bits += cl_len[sym] + (sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u);
+        bits += cl_len[sym] + cl_extra_bits(sym);
     }
-    h.nll = nll; h.nd = nd; h.ncl = ncl; h.ntok = nt; h.bits = bits;
+    h.ncl = ncl; h.bits = bits;
 }
 
 // Sends the header through sink(bits, nbits) (LSB first, nbits <= 16 per call).

@@ -58,13 +58,17 @@ static_assert(kDfMaxDist + kDfSeg + kLook <= kDataRing, "window + segment + look
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 
+// Inclusive sum over the wave in six DPP additions (no LDS traffic): within a row of 16 lanes by row_shr 1, 2, 4, 8
+// (the bank masks keep a lane from adding what lies outside its row), then a row's last lane into the rows behind it.
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
-        if (lane >= (uint32_t)d) v += o;
-    }
+    (void)lane;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v, uint32_t lane)
@@ -103,7 +107,8 @@ struct ChunkLds {
     union {
         uint32_t res[3][kDfSeg];      // 24 KB
         struct {
-            HuffScratch hs;
+            HuffScratch hs;                  // literal/length tree, then the code length code
+            HuffScratch hs_d;                // distance tree (another wave, at the same time)
             uint32_t tile_bits[kChunkTiles]; // bits a tile's tokens take, then their exclusive scan
         } em;
     };
@@ -120,7 +125,7 @@ struct ChunkLds {
     uint32_t finish_done;  // tiles of segment j - 2 whose tokens are counted (the parse waits for all: its prices)
     uint32_t ntok, nmatch; // the parse: tokens / matches of the segments whose tokens are counted (token_counts)
     uint32_t queue[2];    // work items handed out in the current step (the other counter is reset for the next one)
-    uint32_t fixed_bits, extra_bits, total_bits, dyn_bits, use_dynamic;
+    uint32_t fixed_bits, extra_bits, total_bits, dyn_bits, use_dynamic, ghosts;
 };
 static_assert(sizeof(ChunkLds) <= 160 * 1024, "one workgroup per CU");
 
@@ -460,6 +465,125 @@ __device__ __forceinline__ void token_counts(ChunkLds& L, uint32_t seg_rel0, uin
     if (lane == 0u) { L.nmatch = nmatch + all_m; L.ntok = ntok + all_t; }
 }
 
+// ---- code construction by a whole wave: the same results as the serial routines of deflate_core.h ----------------
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// huff_lengths(): the stable sort becomes a rank count (lane = up to five symbols, every lane reads every key), the
+// two-queue merge stays one lane's job, the depths are walked leaf by leaf in parallel.  n <= 320.
+__device__ __forceinline__ void huff_lengths_wave(const uint32_t* freq, uint32_t n, uint32_t max_bits, uint8_t* len, uint32_t* w, uint16_t* parent,
+                                                  uint16_t* order, uint32_t lane)
+{
+    constexpr uint32_t kPer = 5;
+    for (uint32_t shift = 0;; ++shift) {
+        uint32_t key[kPer], rank[kPer];
+        uint32_t zeros = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < kPer; ++s) {
+            const uint32_t i = lane + 64u * s;
+            uint32_t f = 0;
+            if (i < n) {
+                f = freq[i] >> shift;
+                if (f == 0u && freq[i] != 0u) f = 1u;
+                if (f > 0xffffu) f = 0xffffu;
+                w[n + i] = f; // (the upper half of w: the merge's internal nodes come later)
+                zeros += f == 0u ? 1u : 0u;
+            }
+            key[s] = f;
+            rank[s] = 0;
+        }
+        wave_lds_sync();
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t kj = w[n + j];
+#pragma unroll
+            for (uint32_t s = 0; s < kPer; ++s) rank[s] += (kj < key[s] || (kj == key[s] && j < lane + 64u * s)) ? 1u : 0u;
+        }
+        const uint32_t z = wave_sum(zeros, lane); // unused symbols sort first
+        const uint32_t m = n - z;
+#pragma unroll
+        for (uint32_t s = 0; s < kPer; ++s) {
+            const uint32_t i = lane + 64u * s;
+            if (i < n) {
+                if (key[s] == 0u) len[i] = 0u;
+                else if (m == 1u) len[i] = 1u;
+                else { order[rank[s]] = (uint16_t)i; w[rank[s]] = key[s]; }
+            }
+        }
+        if (m <= 1u) return;
+        wave_lds_sync();
+        const uint32_t root = n + m - 2u;
+        if (lane == 0u) { // two-queue merge: leaves z .. n-1 in sorted order, internal nodes n .. n+m-2.  The heads of both
+                          // queues are kept in registers (an empty queue's head weighs more than anything): a pick costs one
+                          // LDS read, and the leaf queue's is issued a pick ahead
+            constexpr uint32_t kNone = 0xffffffffu;
+            uint32_t li = z, ii = n, nn = n;
+            uint32_t wl = w[z], wl1 = z + 1u < n ? w[z + 1u] : kNone, wi = kNone;
+            for (uint32_t k = 0; k + 1u < m; ++k) {
+                uint32_t a, b, wa, wb;
+                if (wl <= wi) { a = li++; wa = wl; wl = wl1; wl1 = li + 1u < n ? w[li + 1u] : kNone; }
+                else { a = ii++; wa = wi; wi = ii < nn ? w[ii] : kNone; }
+                if (wl <= wi) { b = li++; wb = wl; wl = wl1; wl1 = li + 1u < n ? w[li + 1u] : kNone; }
+                else { b = ii++; wb = wi; wi = ii < nn ? w[ii] : kNone; }
+                const uint32_t sum = wa + wb;
+                w[nn] = sum;
+                parent[a] = (uint16_t)nn;
+                parent[b] = (uint16_t)nn;
+                if (ii == nn) wi = sum; // the internal queue was empty: the new node is its head
+                ++nn;
+            }
+        }
+        wave_lds_sync();
+        uint32_t depth[kPer];
+        bool deep = false;
+#pragma unroll
+        for (uint32_t s = 0; s < kPer; ++s) {
+            const uint32_t i = z + lane + 64u * s; // a leaf
+            uint32_t d = 0;
+            if (i < n) {
+                uint32_t node = i;
+                while (node != root && d <= max_bits) { node = parent[node]; ++d; }
+                deep = deep || d > max_bits;
+            }
+            depth[s] = d;
+        }
+        if (__ballot(deep) != 0ull) continue; // deeper than the limit: halve the weights and build again
+#pragma unroll
+        for (uint32_t s = 0; s < kPer; ++s) {
+            const uint32_t i = z + lane + 64u * s;
+            if (i < n) len[order[i]] = (uint8_t)depth[s];
+        }
+        return;
+    }
+}
+// huff_codes(): a symbol's code is the first code of its length plus the symbols of that length in front of it
+__device__ __forceinline__ void huff_codes_wave(const uint8_t* len, uint32_t n, uint32_t* out, uint32_t lane)
+{
+    constexpr uint32_t kPer = 5;
+    uint32_t l[kPer], code[kPer];
+#pragma unroll
+    for (uint32_t s = 0; s < kPer; ++s) { const uint32_t i = lane + 64u * s; l[s] = i < n ? len[i] : 0u; code[s] = 0; }
+    uint32_t first = 0, before = 0; // first code of the length in work, symbols of the previous length
+    for (uint32_t b = 1; b <= (uint32_t)kMaxBits; ++b) {
+        first = (first + before) << 1;
+        uint32_t seen = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < kPer; ++s) {
+            const uint64_t mk = __ballot(l[s] == b);
+            if (l[s] == b) code[s] = first + seen + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull));
+            seen += (uint32_t)__builtin_popcountll(mk);
+        }
+        before = seen;
+    }
+#pragma unroll
+    for (uint32_t s = 0; s < kPer; ++s) {
+        const uint32_t i = lane + 64u * s;
+        if (i < n) out[i] = l[s] ? ((rev_bits(code[s], l[s]) << 8) | l[s]) : 0u;
+    }
+}
+
 // ---- finisher: the tokens of one parsed tile -> symbol counts, match tokens to the scratch, block prices -------------
 __device__ __forceinline__ void finish_tile(ChunkLds& L, const uint32_t* __restrict__ res, uint32_t t, uint32_t tile, uint32_t lane,
                                             uint32_t& fixed_lane, uint32_t& extra_lane, uint32_t* __restrict__ tok)
@@ -600,6 +724,8 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
             }
         }
         if (chunk_step && wave >= 1u && wave <= kDfParseWaves && j >= 1u && j - 1u < nseg) { // a window of segment j - 1 (wave 0 has the step's other serial job)
+            // (waves 1-4 sit on four different SIMDs -- a workgroup's waves go round them -- and that matters: four parsing
+            // waves on ONE SIMD take a fifth longer each, 12.7 instead of 10.4 ms per 64 MiB)
             const uint32_t rel0 = (j - 1u) * kDfSeg;
             const uint32_t m = (len - rel0 < kDfSeg) ? len - rel0 : kDfSeg;
             const uint32_t wa = df_window_begin(wave - 1u), wb = df_window_begin(wave) < m ? df_window_begin(wave) : m;
@@ -639,22 +765,53 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
     __threadfence_block(); // the match tokens in the scratch are read back by every wave of this workgroup
     __syncthreads();
 
-    // ---------------- the codes and the header: one lane, sequential and deterministic (the CPU model runs the same routines) ----------------
+    // ---------------- the codes and the header: wave 0 the literal/length tree, wave 1 the distance tree, then wave 0 the
+    // header.  Deterministic, and the same lengths as the serial routines the CPU model runs (deflate_core.h). ----------------
     HuffScratch& S = L.em.hs;
-    if (threadIdx.x == 0u) {
-        L.freq[256] += 1u; // end of block
-        const bool ghost0 = L.freq[288] == 0u, ghost1 = L.freq[289] == 0u;
-        if (ghost0) L.freq[288] = 1u; // at least two distance codes, as zlib sends
-        if (ghost1) L.freq[289] = 1u;
-        huff_lengths(L.freq, kNumLL, (uint32_t)kMaxBits, L.len, S.w, S.parent, S.order, S.cnt);
-        huff_lengths(L.freq + 288, kNumD, (uint32_t)kMaxBits, L.len + 288, S.w, S.parent, S.order, S.cnt);
-        build_dyn_header(L.len, L.len + 288, S.rle, S.clfreq, S.cllen, S.clcode, S.w, S.parent, S.order, S.cnt, S.hdr);
-        uint32_t db = S.hdr.bits + L.extra_bits;
-        for (uint32_t k = 0; k < 318u; ++k)
-            if (k < (uint32_t)kNumLL || k >= 288u) db += L.freq[k] * (uint32_t)L.len[k];
-        L.use_dynamic = db < L.fixed_bits + L.extra_bits ? 1u : 0u; // (priced with the two codes that may never be sent, as the model does)
-        // what the block will really take: a distance code that exists only to complete the code is never emitted
-        L.dyn_bits = db - (ghost0 ? (uint32_t)L.len[288] : 0u) - (ghost1 ? (uint32_t)L.len[289] : 0u);
+    if (wave == 0u) {
+        if (lane == 0u) L.freq[256] += 1u; // end of block
+        wave_lds_sync();
+        huff_lengths_wave(L.freq, (uint32_t)kNumLL, (uint32_t)kMaxBits, L.len, S.w, S.parent, S.order, lane);
+    } else if (wave == 1u) {
+        HuffScratch& SD = L.em.hs_d;
+        if (lane == 0u) {
+            const bool ghost0 = L.freq[288] == 0u, ghost1 = L.freq[289] == 0u;
+            if (ghost0) L.freq[288] = 1u; // at least two distance codes, as zlib sends
+            if (ghost1) L.freq[289] = 1u;
+            L.ghosts = (ghost0 ? 1u : 0u) | (ghost1 ? 2u : 0u);
+        }
+        wave_lds_sync();
+        huff_lengths_wave(L.freq + 288, (uint32_t)kNumD, (uint32_t)kMaxBits, L.len + 288, SD.w, SD.parent, SD.order, lane);
+    }
+    __syncthreads();
+    if (wave == 0u) {
+        if (lane == 0u) dyn_header_tokens(L.len, L.len + 288, S.rle, S.clfreq, S.hdr);
+        wave_lds_sync();
+        huff_lengths_wave(S.clfreq, (uint32_t)kNumCL, (uint32_t)kMaxCLBits, S.cllen, S.w, S.parent, S.order, lane);
+        wave_lds_sync();
+        if (lane == 0u) {
+            huff_codes(S.cllen, kNumCL, S.clcode, S.cnt);
+            uint32_t ncl = kNumCL;
+            while (ncl > 4u && S.cllen[cl_order(ncl - 1u)] == 0) --ncl;
+            S.hdr.ncl = ncl;
+        }
+        wave_lds_sync();
+        uint32_t part = 0;
+        for (uint32_t t = lane; t < S.hdr.ntok; t += 64u) { const uint32_t sym = S.rle[t] & 0xffu; part += (uint32_t)S.cllen[sym] + cl_extra_bits(sym); }
+        for (uint32_t k = lane; k < 318u; k += 64u)
+            if (k < (uint32_t)kNumLL || k >= 288u) part += L.freq[k] * (uint32_t)L.len[k];
+        const uint32_t sum = wave_sum(part, lane);
+        // header bits alone (for the emission's placement), then the whole block
+        uint32_t hpart = 0;
+        for (uint32_t t = lane; t < S.hdr.ntok; t += 64u) { const uint32_t sym = S.rle[t] & 0xffu; hpart += (uint32_t)S.cllen[sym] + cl_extra_bits(sym); }
+        const uint32_t hsum = wave_sum(hpart, lane);
+        if (lane == 0u) {
+            S.hdr.bits = 3u + 5u + 5u + 4u + 3u * S.hdr.ncl + hsum;
+            const uint32_t db = 3u + 5u + 5u + 4u + 3u * S.hdr.ncl + sum + L.extra_bits;
+            L.use_dynamic = db < L.fixed_bits + L.extra_bits ? 1u : 0u; // (priced with the two codes that may never be sent, as the model does)
+            // what the block will really take: a distance code that exists only to complete the code is never emitted
+            L.dyn_bits = db - ((L.ghosts & 1u) ? (uint32_t)L.len[288] : 0u) - ((L.ghosts & 2u) ? (uint32_t)L.len[289] : 0u);
+        }
     }
     __syncthreads();
 #if defined(SNAPHASH_DEFLATE_STAMPS)
@@ -694,9 +851,9 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
 
     // ---------------- emission: price the tiles, place them, encode into the LDS image, copy out ----------------
     const uint32_t ntiles = (len + 63u) >> 6;
-    if (threadIdx.x == 0u && dynamic) { // the counts are spent: the codes go where they were
-        huff_codes(L.len, kNumLL, L.freq, S.cnt);
-        huff_codes(L.len + 288, kNumD, L.freq + 288, S.cnt);
+    if (dynamic) { // the counts are spent: the codes go where they were
+        if (wave == 0u) huff_codes_wave(L.len, (uint32_t)kNumLL, L.freq, lane);
+        else if (wave == 1u) huff_codes_wave(L.len + 288, (uint32_t)kNumD, L.freq + 288, lane);
     }
     const uint32_t img_words = (nbytes + 3u) >> 2;
     for (uint32_t i = threadIdx.x; i < img_words + 2u; i += kThreads) L.image[i] = 0u; // the ring and the heads are spent

@@ -18,17 +18,23 @@
 //   search    every position of the segment walks its chain (its own link first, so it only ever sees older
 //             positions) up to kDfDepth candidates within the last 28 800 bytes, four links at a time, and leaves
 //             (length, distance, its byte) in an LDS result word;
-//   parse     wave 0, one segment behind: the price parse of deflate_core.h -- the cheapest way through the segment
-//             at prices from the chunk's symbol counts so far.  A shortest path, forward: the ways to the next 64
-//             positions live in ONE register, a lane each; a step offers the position's literal and every length of
-//             its match to them in one masked v_min and shifts the register by a lane (DPP); the way back hops
-//             from token to token through a byte per position -> bitmaps, and the chosen lengths into the results;
+//   parse     waves 1-4, one segment behind, a window (a quarter of the segment) each: the price parse of
+//             deflate_core.h -- the cheapest way through the window at prices from the chunk's symbol counts so
+//             far.  A shortest path, forward: the ways to the next 63 positions live in ONE register, a lane each
+//             (lane = token length); a step offers every length of the position's match to them in one masked
+//             v_min and shifts the register by a lane (DPP), the literal's way stays scalar; the way back hops from
+//             token to token through a byte per position -> bitmaps, and the chosen lengths into the results;
 //   finish    one more segment behind: symbol counts (LDS atomics), match tokens to an HBM scratch (4 B per
-//             MATCH, not per byte), the two block prices.  Search tiles and finish tiles come from one queue.
-// Then one lane builds the dynamic Huffman codes and the block header (deflate_core.h: the CPU model runs the very
-// same routines), every wave prices its tiles, a scan places them, and all waves encode their tokens into an LDS
-// image of the block (the ring's bytes, spent by then) that is copied out in one coalesced sweep.  A chunk ends
-// with an empty stored block (byte aligned, zlib's Z_SYNC_FLUSH); a second kernel concatenates the chunks.
+//             MATCH, not per byte), the two block prices.
+// Only two barriers a step wait for everybody (staging | indexing inside tiles | everything else): the links across
+// tiles announce their progress tile by tile and a searcher waits for its own tile; the finishers count their tiles
+// and the parse waits for the last (its prices are the counts); search tiles and finish tiles come from queues.
+// Then two waves build the dynamic Huffman codes (wave 0 the literal/length tree, wave 1 the distance tree: the sort is
+// a rank count over the wave, the two-queue merge one lane's job, the depths walked leaf by leaf in parallel -- the
+// lengths are those of the serial routines in deflate_core.h, which the CPU model runs), wave 0 the block header;
+// every wave prices its tiles, a scan places them, and all waves encode their tokens into an LDS image of the block
+// (the ring's bytes, spent by then) that is copied out in one coalesced sweep.  A chunk ends with an empty stored
+// block (byte aligned, zlib's Z_SYNC_FLUSH); a second kernel concatenates the chunks.
 //
 // Integer/LDS work with data-dependent control flow: no MFMA.  Algorithmic bytes: 1 read and <= 1.0002 written
 // per input byte (a chunk that does not shrink is stored).  HBM traffic beyond that: the 28 KiB window in front of
@@ -669,11 +675,12 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
     __syncthreads();
 
     // ---------------- the pipeline, per step i ----------------
-    //   all waves   stage the bytes of segment i (kLook ahead); index it inside its tiles (two tiles per wave)
-    //   then        wave 0: the links across tiles | the others: finish segment j - 2 (tiles from a queue)
-    //   then        search chunk segment j = i - nwin (30 tiles from a queue); before they join, waves 1-4 parse a
-    //               window (a quarter) of segment j - 1 each.  Wave 0 turns that parse into tokens at the top of the
-    //               next step (token_counts), in front of the barriers the finishers wait behind.
+    //   all waves   stage the bytes of segment i (kLook ahead) | barrier | index it inside its tiles (two tiles per wave) | barrier
+    //   then        wave 0: the links across tiles; everybody: finish segment j - 2 (tiles from a queue); waves 1-4:
+    //               a window (a quarter) of segment j - 1 each, once the finishers are through; everybody: search chunk
+    //               segment j = i - nwin (30 tiles from a queue, a tile as soon as its links are complete) | barrier
+    //   Wave 0 turns a parsed segment's per-tile match counts into token bases at the top of the next step
+    //   (token_counts), in front of the barriers the finishers wait behind.
     uint32_t fixed_lane = 0, extra_lane = 0;
     const uint32_t steps = nwin + nseg + 2u;
 #if defined(SNAPHASH_DEFLATE_STAMPS)

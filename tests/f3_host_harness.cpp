@@ -172,5 +172,8 @@ int f3_tar_header_of(const char* name, int64_t size, uint8_t* out512)
     m.mtime = 1;
     return tar_header(m, out512);
 }
+// the price parse's arithmetic (deflate_core.h)
+uint32_t f3_ilog(uint32_t x) { return df_ilog(x); }
+uint32_t f3_price(uint32_t f, uint32_t log_total, uint32_t cap) { return df_price(f, log_total, cap); }
 void f3_free(void* p) { free(p); }
 }

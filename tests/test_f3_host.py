@@ -75,10 +75,36 @@ def test_model_of_the_deflate_kernel_is_valid_gzip(f3):
         assert gzip.decompress(gz2) == data and len(gz2) >= len(gz) - 64, name
         if name in ("zeros", "ff", "text"):
             assert len(gz) < len(data) // 8, (name, len(gz), len(data))
-        if name == "prose":  # random words out of 500: hash chains + dynamic codes, within a few percent of zlib -6
-            assert len(gz) < len(zlib.compress(data, 6)) * 1.05, (name, len(gz), len(zlib.compress(data, 6)))
+        if name == "prose":  # random words out of 500: hash chains, the price parse, dynamic codes: under zlib -6 (not a parity
+            # statement -- the reference's gzip-9 bytes are not reproduced -- a guard against the parse getting worse)
+            assert len(gz) < len(zlib.compress(data, 6)), (name, len(gz), len(zlib.compress(data, 6)))
         if name in ("random", "random 64K", "random 200000", "high bytes"):
             assert len(gz) <= len(data) + 10 * (len(data) // 65536 + 1) + 20, (name, len(gz))
+
+
+def test_price_arithmetic_of_the_parse(f3):
+    """deflate_core.h's df_ilog / df_price, which the kernel and its model share: log2 in quarter bits, exact at the powers
+    of two, never decreasing, never above the real logarithm nor 0.35 bits under it (the mantissa is linear, then cut); a price is at least one bit, at
+    most its cap, and falls as the symbol gets more frequent."""
+    import math
+    f3.f3_ilog.argtypes = [ctypes.c_uint32]
+    f3.f3_ilog.restype = ctypes.c_uint32
+    f3.f3_price.argtypes = [ctypes.c_uint32] * 3
+    f3.f3_price.restype = ctypes.c_uint32
+    prev = 0
+    for x in list(range(1, 5000)) + [2**k + d for k in range(13, 31) for d in (-1, 0, 1)] + [2**32 - 1]:
+        v = f3.f3_ilog(x)
+        if x < 5000:
+            assert v >= prev, x
+            prev = v
+        assert 4 * math.log2(x) - 1.4 < v <= 4 * math.log2(x) + 1e-9, (x, v)
+    for k in range(32):
+        assert f3.f3_ilog(1 << k) == 4 * k
+    total = 20000
+    lt = f3.f3_ilog(total + 1)
+    prices = [f3.f3_price(f, lt, 56) for f in range(0, total + 1, 7)]
+    assert all(4 <= p <= 56 for p in prices) and prices == sorted(prices, reverse=True)
+    assert f3.f3_price(0, lt, 56) == 56 and f3.f3_price(total, lt, 56) == 4 and f3.f3_price(total // 2, lt, 56) in (4, 5)
 
 
 def test_crc32_and_combine_match_zlib(f3):

@@ -55,6 +55,7 @@ def make(target):
 
 
 t_end = time.time() + budget
+t_note = time.time() + 60.0
 it = 0
 replay = int(os.environ.get("SOAK_REPLAY", "-1"))  # regenerate the inputs up to this iteration without compressing them, then hammer that one
 total = 0
@@ -91,6 +92,9 @@ while time.time() < t_end:
     assert gz == model, ("model", it, target, staging)
     it += 1
     total += len(data)
+    if time.time() >= t_note:  # (a run that says nothing for minutes is taken for hung)
+        print("  ... %d inputs, %.1f MiB so far" % (it, total / 2**20), flush=True)
+        t_note = time.time() + 60.0
 for c in ctxs.values():
     c.close()
 print("soak_deflate: %d inputs, %.1f MiB, all inflate to their input and equal the CPU model" % (it, total / 2**20))

@@ -114,9 +114,12 @@ static_assert(kDfMaxDist % kDfSeg == 0 && kDfSeg % 64 == 0 && kDfSeg % 16 == 0, 
 // the powers of two, at least one bit and at most 14 (12 for a distance symbol).  Extra bits cost what they are.
 // A match of kDfLongMatch bytes or more is not weighed: the path goes through its position and takes all of it.
 // Among equally cheap ways to a position the longest last token wins.  A segment is parsed as kDfParseWaves windows,
-// one wave each, all at the segment's prices: no token leaves its window.
+// one wave each, all at the segment's prices: no token leaves its window.  A window ends at the last position of the
+// kDfCutSpan up to its nominal end that no match from in front of it reaches across (every way passes such a position
+// anyhow: cutting there costs nothing), at the nominal end itself when there is none.
 constexpr uint32_t kDfParseWaves = 4;
-// where window w of a segment begins, in tiles of 64 positions (8 + 8 + 7 + 7 tiles; a short last segment ends them early)
+constexpr uint32_t kDfCutSpan = 64;
+// where window w of a segment nominally begins (8 + 8 + 7 + 7 tiles of 64 positions; a short last segment ends them early)
 DF_HD uint32_t df_window_begin(uint32_t w) { return w < 2u ? w * 512u : (w == 2u ? 1024u : (w == 3u ? 1472u : kDfSeg)); }
 static_assert(kDfSeg == 1920, "the windows above are cut for this segment");
 constexpr uint32_t kDfPriceUnit = 4;

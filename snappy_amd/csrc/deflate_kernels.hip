@@ -77,6 +77,18 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t lane)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
     return v;
 }
+// The same with max (values >= 0: the lanes a step leaves out contribute 0).
+__device__ __forceinline__ uint32_t wave_scan_max_incl(uint32_t v)
+{
+    const auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v, uint32_t lane)
 {
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v, lane), 63);
@@ -127,6 +139,7 @@ struct ChunkLds {
     uint8_t from8[kDfSeg + 64];  // the parse: length of the last token of the cheapest way to each position of the segment
     uint8_t price_ll[288];       // the parse: prices (quarter bits) of the literal/length symbols, of the distance symbols
     uint8_t price_d[32];
+    uint32_t bounds[kDfParseWaves + 1u]; // the parse: where the windows of the segment in work begin and end
     uint32_t across_done;  // tiles of the step's segment whose links are complete (the searchers of a tile wait for it)
     uint32_t finish_done;  // tiles of segment j - 2 whose tokens are counted (the parse waits for all: its prices)
     uint32_t ntok, nmatch; // the parse: tokens / matches of the segments whose tokens are counted (token_counts)
@@ -320,9 +333,40 @@ __device__ __forceinline__ uint32_t min_and_shift(uint32_t w, uint32_t cand, uin
 }
 // One window [wa, wb) of segment [seg_rel0, seg_rel0 + m): every wave that parses writes the same price tables
 // (same inputs, same values: whichever write lands last changes nothing), then works on positions of its own.
-__device__ __forceinline__ void parse_window(ChunkLds& L, uint32_t* res, uint32_t seg_rel0, uint32_t wa, uint32_t wb, uint32_t lane)
+// Where window wi of the segment's m positions begins (deflate_core.h): at its nominal place, or up to kDfCutSpan - 1
+// in front of it at the last position no match from further in front reaches across: six tiles, a running maximum of
+// position + reach.  Worked out at the top of the step, before any window is parsed (a parse writes the lengths it
+// chose over the ones found).
+__device__ __forceinline__ uint32_t window_bound(const uint32_t* res, uint32_t m, uint32_t wi, uint32_t lane)
+{
+    if (wi == 0u) return 0u;
+    const uint32_t b = df_window_begin(wi);
+    if (b >= m) return m;
+    static_assert(kDfCutSpan == 64u, "the candidates are the positions of one tile");
+    const uint32_t t1 = b >> 6; // the nominal place is a whole tile; a match is at most 258 long: tiles t1 - 6 .. t1 - 1 say it all
+    uint32_t running = 0, v = 0;
+    for (uint32_t t = t1 - 6u; t < t1; ++t) {
+        const uint32_t ppos = t * 64u + lane, ml = res[ppos] & 0x1ffu, room = m - ppos;
+        const uint32_t mlc = ml < room ? ml : room;
+        v = ppos + (mlc ? mlc : 1u);
+        if (t + 1u < t1) {
+            const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_max_incl(v), 63);
+            running = running > top ? running : top;
+        }
+    }
+    const uint32_t incl = wave_scan_max_incl(v); // the last tile: positions b - 64 .. b - 1
+    const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xf, 0xf, false); // wave_shr:1: the lanes in front
+    const uint32_t far = running > below ? running : below;
+    const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if ((running > all ? running : all) <= b) return b;
+    const uint64_t ok = __ballot(lane >= 1u && far <= (t1 - 1u) * 64u + lane);
+    return ok ? (t1 - 1u) * 64u + 63u - (uint32_t)__builtin_clzll(ok) : b;
+}
+
+__device__ __forceinline__ void parse_window(ChunkLds& L, uint32_t* res, uint32_t seg_rel0, uint32_t m, uint32_t wi, uint32_t lane)
 {
     const uint32_t tile0 = seg_rel0 >> 6;
+    const uint32_t wa = L.bounds[wi], wb = L.bounds[wi + 1u];
     const uint32_t ntok = L.ntok, nmatch = L.nmatch;
     if (ntok < kDfPriceWarm) {
         for (uint32_t k = lane; k < 288u; k += 64u) L.price_ll[k] = (uint8_t)(k < 256u ? kDfLitPrice0 : kDfLenPrice0);
@@ -422,11 +466,13 @@ __device__ __forceinline__ void parse_window(ChunkLds& L, uint32_t* res, uint32_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // The tokens of the window (its tiles are its own: windows begin at whole tiles).  A token ends where the next
-    // begins or where the window ends: lengths, which tokens are matches, the chosen lengths into the result words.
+    // The tokens of the window.  A token ends where the next begins or where the window ends: lengths, which tokens are
+    // matches, the chosen lengths into the result words.  A window's first and last tile may be shared with its
+    // neighbours, which are at work at the same time: only the bits of this window's positions are looked at, and what
+    // goes into the per-tile words goes there atomically.
     const auto starts_of = [&](uint32_t t) -> uint64_t {
         uint64_t v = t < tile_end ? L.startbits[tile0 + t] : 0ull;
-        if ((wb >> 6) == t) v |= 1ull << (wb & 63u); // the window's end counts as a start here
+        if ((wb >> 6) == t) v = (v & ((1ull << (wb & 63u)) - 1ull)) | (1ull << (wb & 63u)); // the window's end counts as a start here; behind it is the neighbour's
         return v;
     };
     uint64_t sm_v = starts_of(wa >> 6);
@@ -434,7 +480,7 @@ __device__ __forceinline__ void parse_window(ChunkLds& L, uint32_t* res, uint32_
         const uint64_t nx_v = starts_of(t + 1u);
         const uint32_t r = res[t * 64u + lane];
         const uint32_t ppos = t * 64u + lane;
-        const bool my_start = ppos < wb && ((sm_v >> lane) & 1ull);
+        const bool my_start = ppos >= wa && ppos < wb && ((sm_v >> lane) & 1ull);
         const uint32_t room = ppos < wb ? wb - ppos : 0u;
         const uint32_t ml = r & 0x1ffu;
         const uint32_t mlc = ml < room ? ml : room;
@@ -444,11 +490,9 @@ __device__ __forceinline__ void parse_window(ChunkLds& L, uint32_t* res, uint32_
         const bool my_match = my_start && tl >= kDfMinMatch;
         const uint64_t mk = __ballot(my_match);
         if (my_match) res[t * 64u + lane] = (r & ~0x1ffu) | tl;
-        const uint64_t real = __ballot(my_start);
-        if (lane == 0u) {
-            L.startbits[tile0 + t] = real;
-            L.matchbits[tile0 + t] = mk;
-            L.match_base[tile0 + t] = (uint32_t)__builtin_popcountll(mk); // a count: token_counts makes it the base
+        if (lane == 0u && mk != 0ull) {
+            atomicOr(&L.matchbits[tile0 + t], mk);
+            atomicAdd(&L.match_base[tile0 + t], (uint32_t)__builtin_popcountll(mk)); // a count: token_counts makes it the base
         }
         sm_v = nx_v;
     }
@@ -667,7 +711,11 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
         *reinterpret_cast<uint4*>(L.data + at) = v;
         if (at == 0u) *reinterpret_cast<uint4*>(L.data + kDataRing) = v;
     }
-    for (uint32_t i = threadIdx.x; i < kChunkTiles; i += kThreads) L.startbits[i] = 0ull; // the parse ORs a tile's starts together
+    for (uint32_t i = threadIdx.x; i < kChunkTiles; i += kThreads) { // the parse ORs / adds a tile's starts, matches and match count together
+        L.startbits[i] = 0ull;
+        L.matchbits[i] = 0ull;
+        L.match_base[i] = 0u;
+    }
     if (threadIdx.x == 0u) { L.queue[0] = 0u; L.queue[1] = 0u; L.ntok = 0u; L.nmatch = 0u; }
     __syncthreads();
 
@@ -696,6 +744,12 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
         const uint32_t fin_rel0 = (j - 2u) * kDfSeg; // (meaningful when do_finish)
         const uint32_t fin_m = do_finish ? ((len - fin_rel0 < kDfSeg) ? len - fin_rel0 : kDfSeg) : 0u;
         if (do_finish && wave == 0u) STAMP(t_par, token_counts(L, fin_rel0, fin_m, lane));
+        if (chunk_step && j >= 1u && j - 1u < nseg && wave >= 1u && wave <= kDfParseWaves) { // the windows of the segment parsed in this step
+            const uint32_t rel0 = (j - 1u) * kDfSeg;
+            const uint32_t m = (len - rel0 < kDfSeg) ? len - rel0 : kDfSeg;
+            const uint32_t b = window_bound(L.res[(j - 1u) % 3u], m, wave, lane);
+            if (lane == 0u) { L.bounds[wave] = b; if (wave == 1u) L.bounds[0] = 0u; }
+        }
         if (threadIdx.x == 0u) { L.across_done = 0u; L.finish_done = 0u; }
         const bool do_index = i < nwin + nseg;
         if (do_index) {
@@ -732,11 +786,10 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
             // waves on ONE SIMD take a fifth longer each, 12.7 instead of 10.4 ms per 64 MiB)
             const uint32_t rel0 = (j - 1u) * kDfSeg;
             const uint32_t m = (len - rel0 < kDfSeg) ? len - rel0 : kDfSeg;
-            const uint32_t wa = df_window_begin(wave - 1u), wb = df_window_begin(wave) < m ? df_window_begin(wave) : m;
             const uint32_t fin_tiles = (fin_m + 63u) >> 6;
             STAMP(t_wait, while (__hip_atomic_load(&L.finish_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < fin_tiles) __builtin_amdgcn_s_sleep(1));
             __builtin_amdgcn_s_setprio(3);
-            STAMP(t_par, parse_window(L, L.res[(j - 1u) % 3u], rel0, wa < m ? wa : m, wb, lane));
+            STAMP(t_par, parse_window(L, L.res[(j - 1u) % 3u], rel0, m, wave - 1u, lane));
             __builtin_amdgcn_s_setprio(0);
         }
         if (chunk_step && j < nseg) {

@@ -7,7 +7,7 @@
 //            if it agrees with p in the four bytes ending at the current best length (it cannot be longer otherwise);
 //            longer wins, the first found keeps ties; nice ends the walk, good cuts the links left to a quarter;
 //            a 3-byte match farther than too_far is dropped
-//   parse    the price parse of deflate_core.h, segment (1 920 positions) by segment, window (512 or 448) by window: forward,
+//   parse    the price parse of deflate_core.h, segment (1 920 positions) by segment, window (about 512 or 448: deflate_core.h) by window: forward,
 //            every position offering a literal and the first L bytes of its match (L from 3, or 4 for a distance
 //            beyond too_far, to 62) to the positions behind it; a match of 63 or more ends the run: the way to its
 //            position is traced back, the match is taken whole, and a new run starts behind it
@@ -107,8 +107,27 @@ inline void parse_chunk(const uint8_t* in, size_t n_in, size_t c0, size_t c1, co
             for (uint32_t d = 0; d < (uint32_t)kNumD; ++d) dsym_price[d] = nmatch ? df_price(f_d[d], dt, kDfDistCap) : kDfDistPrice0;
         }
         std::fill(tok_len.begin(), tok_len.end(), 0u); // tok_len[i] != 0: a token of that length starts at i
-        for (uint32_t wi = 0; wi < kDfParseWaves && df_window_begin(wi) < m; ++wi) { // the windows of the segment: no token leaves its own
-        const uint32_t wa = df_window_begin(wi), wb = std::min(m, df_window_begin(wi + 1u));
+        // where the windows end: far[p] = how far the matches of the positions in front of p reach
+        uint32_t bounds[kDfParseWaves + 1u];
+        bounds[0] = 0;
+        {
+            std::vector<uint32_t> far(m + 1u, 0);
+            uint32_t reach = 0;
+            for (uint32_t i = 0; i < m; ++i) {
+                far[i] = reach;
+                reach = std::max(reach, i + std::max(1u, std::min(mlen[g0 + i], m - i)));
+            }
+            far[m] = reach;
+            for (uint32_t wi = 1; wi <= kDfParseWaves; ++wi) {
+                uint32_t b = std::min(m, df_window_begin(wi));
+                if (b < m)
+                    for (uint32_t p = b; p + kDfCutSpan > b; --p)
+                        if (far[p] <= p) { b = p; break; }
+                bounds[wi] = b;
+            }
+        }
+        for (uint32_t wi = 0; wi < kDfParseWaves && bounds[wi] < m; ++wi) { // the windows of the segment: no token leaves its own
+        const uint32_t wa = bounds[wi], wb = bounds[wi + 1u];
         uint32_t pos = wa;
         while (pos < wb) {
             const uint32_t run0 = pos;

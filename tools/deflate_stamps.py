@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Phase breakdown of deflate_chunks_kernel (a build with -DSNAPHASH_DEFLATE_STAMPS prints s_memtime deltas of chunk 37):
-SNAPHASH_LIB=snappy_amd/variants/libsnaphash_stamps.so python tools/deflate_stamps.py [text|src]"""
+make -C snappy_amd/csrc stamps && SNAPHASH_LIB=snappy_amd/variants/libsnaphash_stamps.so python tools/deflate_stamps.py
+Without SNAPHASH_LIB: the shipped library, kernel time only."""
 import os
 import sys
 import time

@@ -18,8 +18,13 @@
  *   - Return 0 on success, a negative SNAPHASH_E* code otherwise.  As in the
  *     reference (build.go:242-244) the first per-file error fails the whole
  *     batch and no output may be trusted.
- *   - Hashing runs on the GPU only.  There is no CPU fallback: without a usable
- *     gfx950 device snaphash_init fails with SNAPHASH_EDEVICE.
+ *   - There is no CPU fallback: without a usable gfx950 device snaphash_init fails with
+ *     SNAPHASH_EDEVICE, and no error path re-routes a call.  Where a call's bytes are hashed is
+ *     a planned decision (snaphash_config.host_threads): the HIP kernels take what many
+ *     streams in parallel make fast, the library's own host SHA-512 (hostsha.cpp) takes what
+ *     one SHA-512 stream at ~45 MB/s on the GPU would make slower than the reference's single
+ *     goroutine; snaphash_stats_ex says which bytes went where, SNAPHASH_FLAG_GPU_ONLY keeps
+ *     every byte on the GPU.
  *   - The caller owns every input and output buffer; the library keeps no caller
  *     pointer past return.  Only snaphash_tree's yaml_out and snaphash_walk's
  *     record set are library-allocated (snaphash_free / snaphash_records_free).
@@ -228,7 +233,7 @@ typedef struct snaphash_targz_stats { /* of the most recent snaphash_tar_create 
     uint64_t tar_bytes;     /* uncompressed stream */
     uint64_t gz_bytes;      /* bytes written */
     uint64_t members;       /* tar members */
-    uint64_t chunks;        /* 16 KiB deflate chunks */
+    uint64_t chunks;        /* 64 KiB deflate chunks (one DEFLATE block, one workgroup each) */
     uint64_t stored_chunks; /* of those, emitted as stored blocks (did not shrink) */
     double deflate_ms;      /* deflate + concatenation kernels, HIP events */
     double fill_ms;         /* assembling the tar stream in pinned memory (header records, parallel pread) */

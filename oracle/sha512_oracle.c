@@ -34,6 +34,8 @@
 #include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <locale.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -254,20 +256,58 @@ static int nm_float(const char *s) /* strconv.ParseFloat, decimal grammar + inf/
     }
     return *p == 0;
 }
-static int nm_int(const char *s) /* ParseInt/ParseUint base 0 syntax (a range error still ends as a float) */
+/* resolve.go asks strconv with `err == nil`, and a value out of range is an error there: what follows answers "does
+ * the call succeed", by the C library's own conversions (strtoull / strtod: ERANGE is Go's ErrRange; both round a
+ * decimal correctly, so the overflow threshold is the same one). */
+static int nm_uint_digits(const char *s, int base, unsigned long long *mag) /* all of s digits of `base` and the value fits 64 bits */
 {
-    if (*s == '+' || *s == '-') s++;
     if (!*s) return 0;
-    if (s[0] == '0' && (s[1] == 'x' || s[1] == 'X')) { s += 2; if (!*s) return 0; while (nm_hex(*s)) s++; return *s == 0; }
-    while (nm_digit(*s)) s++;
-    return *s == 0;
+    for (const char *q = s; *q; q++) {
+        int d = nm_digit(*q) ? *q - '0' : (*q >= 'a' && *q <= 'f') ? *q - 'a' + 10 : (*q >= 'A' && *q <= 'F') ? *q - 'A' + 10 : 99;
+        if (d >= base) return 0;
+    }
+    char *end = 0;
+    errno = 0;
+    *mag = strtoull(s, &end, base);
+    return errno == 0 && end && *end == 0;
 }
-static int nm_bin(const char *s) /* resolve.go: 0b / -0b */
+static int nm_int_base(const char *s, int base, int try_unsigned) /* ParseInt(s, base, 64), then ParseUint if asked */
+{
+    int neg = *s == '-', sign = *s == '+' || *s == '-';
+    const char *q = s + sign;
+    if (base == 0) { /* Go before 1.13: 0x hex, a leading 0 octal, else decimal */
+        if (q[0] == '0' && (q[1] == 'x' || q[1] == 'X')) { base = 16; q += 2; }
+        else base = q[0] == '0' ? 8 : 10;
+    }
+    unsigned long long mag;
+    if (!nm_uint_digits(q, base, &mag)) return 0;
+    if (neg ? mag <= 9223372036854775808ull : mag <= 9223372036854775807ull) return 1;
+    return try_unsigned && !sign;
+}
+static int nm_int(const char *s) { return nm_int_base(s, 0, 1); }
+static int nm_float_ok(const char *s) /* ParseFloat(s, 64) without ErrRange */
+{
+    if (!nm_float(s)) return 0;
+    const char *q = s + (*s == '+' || *s == '-');
+    if (!nm_digit(*q) && *q != '.') return 1; /* inf, infinity, nan */
+    static locale_t cloc;
+    if (!cloc) cloc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+    errno = 0;
+    double v = cloc ? strtod_l(s, 0, cloc) : strtod(s, 0);
+    return !(v == HUGE_VAL || v == -HUGE_VAL); /* underflow to zero is no error in Go */
+}
+static int nm_bin_spelling(const char *s) /* 0b / -0b followed by binary digits only */
 {
     if (*s == '-') s++;
     if (s[0] != '0' || s[1] != 'b' || !s[2]) return 0;
     for (s += 2; *s; s++) if (*s != '0' && *s != '1') return 0;
     return 1;
+}
+static int nm_bin(const char *s) /* resolve.go: ParseInt(plain[2:], 2, 64) then ParseUint; behind -0b ParseInt alone */
+{
+    if (!strncmp(s, "0b", 2)) return nm_int_base(s + 2, 2, 1);
+    if (!strncmp(s, "-0b", 3)) return nm_int_base(s + 3, 2, 0);
+    return 0;
 }
 static int nm_version_dependent(const char *s)
 {
@@ -284,7 +324,7 @@ static int nm_version_dependent(const char *s)
         return has_p;
     }
     if (q[1] == 'b' || q[1] == 'B') {
-        if (nm_bin(s)) return 0;
+        if (nm_bin_spelling(s)) return 0;
         for (q += 2; *q; q++) if (*q != '0' && *q != '1') return 0;
         return 1;
     }
@@ -320,13 +360,13 @@ static int nm_resolves(const char *s)
     if (!hm && !hn && !hd) return strcmp(s, "<<") == 0 ? -1 : 0;
     for (int i = 0; mapped[i]; i++) if (!strcmp(s, mapped[i])) return 1;
     if (hm) return 0;
-    if (hd) return nm_float(s);
+    if (hd) return nm_float_ok(s);
     char plain[4200];
     size_t k = 0;
     for (const char *p = s; *p && k + 1 < sizeof plain; p++) if (*p != '_') plain[k++] = *p;
     plain[k] = 0;
     if (nm_version_dependent(plain)) return -1;
-    return nm_int(plain) || nm_float(plain) || nm_bin(plain);
+    return nm_int(plain) || nm_float_ok(plain) || nm_bin(plain);
 }
 static int nm_decode(const unsigned char *p, uint32_t *cp) /* bytes of the well-formed UTF-8 sequence at p, 0 if none */
 {

@@ -1,13 +1,11 @@
-// hostsha.cpp -- the library's own SHA-512 on host cores, used by the opt-in
-// hybrid scheduler (snaphash_config.host_threads > 0): streams whose single-stream
-// time on the GPU would exceed the batch makespan (a lone stream advances at
-// ~45 MB/s on MI355X, a host core at ~1.4 GB/s) are hashed here, concurrently
-// with the GPU batch -- and by the data.tar.gz producer for the archive digest, the
-// one stream of that pass that cannot be parallel.  Same compression function as the kernels (sha512_core.h,
-// FIPS 180-4), continuing from any chaining value, so a stream may also start on
-// the GPU and finish here.  This is not a fallback: without a gfx950 device
-// snaphash_init still fails, and with host_threads == 0 (the default) nothing in
-// this file runs.
+// hostsha.cpp -- the library's own SHA-512 on host cores.  It runs in the DEFAULT configuration (ABI 3+): the
+// planner of snaphash_api.cpp (plan_host_streams) hands it every stream that would be slower on the GPU than
+// on a host core -- a lone stream advances at ~45 MB/s on MI355X, a host core does ~1.4 GB/s -- concurrently with
+// the GPU batch: the package's data.tar.gz, a 1 GiB member, and whole batches too small to repay a kernel launch
+// (the literal one-file helpers.Sha512sum call).  The data.tar.gz producer uses it for the archive digest, the one
+// stream of that pass that cannot be parallel.  Same compression function as the kernels (sha512_core.h,
+// FIPS 180-4), continuing from any chaining value.  This is not a fallback: without a gfx950 device snaphash_init
+// still fails; only SNAPHASH_FLAG_GPU_ONLY keeps this file idle.
 //
 // What it computes is helpers.Sha512sum (reference helpers/helpers.go:187-201):
 // io.Copy in chunks into crypto/sha512, i.e. streaming SHA-512 to EOF.

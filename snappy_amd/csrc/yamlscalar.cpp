@@ -67,25 +67,110 @@ bool go_parse_float_ok(const std::string& s)
     return i == n;
 }
 
-// strconv.ParseInt/ParseUint(s, 0, 64) succeeding OR failing only by range (then ParseFloat takes the digits): an
-// optional sign, then 0x hex digits, or decimal/octal digits.  "08" is no integer in base 0 but it is a float.
-bool go_int_syntax(const std::string& s)
+// ---- what strconv answers with err == nil -----------------------------------------------------------------------
+// resolve.go (yaml.v2 @ 49c95bdc) takes a scalar for a number only when the strconv call returns NO error, and a value
+// out of range is an error (ErrRange): "1e999", a 0x literal of more than 64 bits or 65 binary digits stay strings and
+// are written plain.
+
+// magnitude of a run of digits in `base`; false = a character that is no digit of that base (or no digit at all)
+bool parse_magnitude(const std::string& s, size_t i, unsigned base, uint64_t* mag, bool* overflow)
 {
-    size_t i = 0;
-    const size_t n = s.size();
-    if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
-    if (i >= n) return false;
-    if (s[i] == '0' && i + 1 < n && (s[i + 1] == 'x' || s[i + 1] == 'X')) {
-        i += 2;
-        if (i >= n) return false;
-        for (; i < n; ++i) if (!is_hex((unsigned char)s[i])) return false;
-        return true;
+    if (i >= s.size()) return false;
+    unsigned __int128 v = 0;
+    *overflow = false;
+    for (; i < s.size(); ++i) {
+        const unsigned char c = (unsigned char)s[i];
+        unsigned d;
+        if (is_digit(c)) d = c - '0';
+        else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+        else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+        else return false;
+        if (d >= base) return false;
+        v = v * base + d;
+        if (v >> 64) { *overflow = true; v &= ~(unsigned __int128)0 >> 64; } // keep scanning: a bad digit further on is a syntax error, not a range error
     }
-    for (; i < n; ++i) if (!is_digit((unsigned char)s[i])) return false;
+    *mag = (uint64_t)v;
     return true;
 }
 
-// resolve.go: binary integers written 0b / -0b (yaml.v2 handles them itself, whatever the Go version)
+// strconv.ParseInt(s, base, 64) == nil or strconv.ParseUint(s, base, 64) == nil, as resolve.go tries them in turn.
+// base 0 (Go before 1.13): "0x" hex, a leading "0" octal, decimal otherwise.  ParseUint takes no sign.
+bool go_int_ok(const std::string& s, unsigned base, bool try_unsigned)
+{
+    size_t i = 0;
+    const bool neg = !s.empty() && s[0] == '-';
+    const bool sign = !s.empty() && (s[0] == '+' || s[0] == '-');
+    if (sign) i = 1;
+    if (i >= s.size()) return false;
+    if (base == 0) {
+        if (s[i] == '0' && i + 1 < s.size() && (s[i + 1] == 'x' || s[i + 1] == 'X')) { base = 16; i += 2; }
+        else if (s[i] == '0') base = 8;
+        else base = 10;
+    }
+    uint64_t mag = 0;
+    bool overflow = false;
+    if (!parse_magnitude(s, i, base, &mag, &overflow)) return false;
+    if (overflow) return false;
+    if (neg ? mag <= (1ull << 63) : mag <= (1ull << 63) - 1) return true; // ParseInt
+    return try_unsigned && !sign;                                         // ParseUint
+}
+
+// A decimal that strconv.ParseFloat (correctly rounded, like every IEEE strtod) turns into +-Inf: ErrRange.  Exact and
+// locale-free: the digits against 2^1024 - 2^970, the midpoint between the largest double and 2^1024 (a tie rounds to
+// even, which is up).  s has passed go_parse_float_ok's decimal grammar.  Underflow to zero is no error in Go.
+bool decimal_float_overflows(const std::string& s)
+{
+    static const char kLimit[] = // 2^1024 - 2^970, 309 digits
+        "17976931348623158079372897140530341507993413271003782693617377898044496829276475094664901797758720709633028641669288"
+        "79109465555478519404026306574886715058206819089020007083836762738548458177115317644757302700698555713669596228429148"
+        "19860834936475292719074168444365510704342711559699508093042880177904174497792";
+    size_t i = 0;
+    const size_t n = s.size();
+    if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+    std::string digits;
+    long point = 0;
+    for (; i < n && is_digit((unsigned char)s[i]); ++i) { digits += s[i]; ++point; }
+    if (i < n && s[i] == '.') for (++i; i < n && is_digit((unsigned char)s[i]); ++i) digits += s[i];
+    long exp10 = 0;
+    if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+        ++i;
+        bool eneg = false;
+        if (i < n && (s[i] == '+' || s[i] == '-')) { eneg = s[i] == '-'; ++i; }
+        for (; i < n && is_digit((unsigned char)s[i]); ++i) if (exp10 < 100000000) exp10 = exp10 * 10 + (s[i] - '0');
+        if (eneg) exp10 = -exp10;
+    }
+    size_t lead = 0;
+    while (lead < digits.size() && digits[lead] == '0') ++lead;
+    if (lead == digits.size()) return false; // zero
+    digits.erase(0, lead);
+    const long mag10 = point - (long)lead + exp10; // value = 0.digits x 10^mag10
+    if (mag10 != 309) return mag10 > 309;
+    for (size_t k = 0; k < 309; ++k) { // digits, padded with zeros, against the limit
+        const char d = k < digits.size() ? digits[k] : '0';
+        if (d != kLimit[k]) return d > kLimit[k];
+    }
+    return true; // equal up to 309 digits: at or above the midpoint
+}
+
+bool go_float_ok(const std::string& s)
+{
+    if (!go_parse_float_ok(s)) return false;
+    const size_t i = (s[0] == '+' || s[0] == '-') ? 1 : 0;
+    if (i < s.size() && !is_digit((unsigned char)s[i]) && s[i] != '.') return true; // inf, infinity, nan
+    return !decimal_float_overflows(s);
+}
+
+// resolve.go: binary integers written 0b / -0b (yaml.v2 handles them itself, before Go's strconv learnt the prefix):
+// ParseInt(plain[2:], 2, 64), then ParseUint; behind "-0b" ParseInt(plain[3:], 2, 64) alone.  strconv takes a sign
+// there too ("0b-101" is -5).
+bool yaml_binary_int_ok(const std::string& s)
+{
+    if (s.compare(0, 2, "0b") == 0) return go_int_ok(s.substr(2), 2, true);
+    if (s.compare(0, 3, "-0b") == 0) return go_int_ok(s.substr(3), 2, false);
+    return false;
+}
+
+// the spelling alone, whatever the range (go_version_dependent below asks)
 bool yaml_binary_int(const std::string& s)
 {
     size_t i = (s.size() > 0 && s[0] == '-') ? 1 : 0;
@@ -168,11 +253,11 @@ int resolves_to_non_string(const std::string& s)
     for (int i = 0; mapped[i]; ++i)
         if (s == mapped[i]) return 1;
     if (hint_m) return 0;
-    if (hint_dot) return go_parse_float_ok(s) ? 1 : 0;
+    if (hint_dot) return go_float_ok(s) ? 1 : 0;
     std::string plain; // strings.Replace(in, "_", "", -1)
     for (char c : s) if (c != '_') plain += c;
     if (go_version_dependent(plain)) return -1;
-    if (go_int_syntax(plain) || go_parse_float_ok(plain) || yaml_binary_int(plain)) return 1;
+    if (go_int_ok(plain, 0, true) || go_float_ok(plain) || yaml_binary_int_ok(plain)) return 1;
     return 0;
 }
 

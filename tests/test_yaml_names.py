@@ -29,6 +29,16 @@ NAMES_RESOLVED = {  # yaml.v2 double-quotes what would read back as bool / null 
     "+.inf": '"+.inf"', ".5": '".5"', ".NaN": '".NaN"', "-1.5e-3": '"-1.5e-3"', "+Inf": '"+Inf"', "1:30": '"1:30"',
     "-12:30:00.5": '"-12:30:00.5"',
 }
+# resolve.go takes a scalar for a number only when strconv returns err == nil, and a value out of range IS an error
+# (ErrRange): a float that overflows a double, a 0x literal or decimal of more than 64 bits that is no float either, 65 binary
+# digits -- all stay strings, written plain.  Beside each the neighbour that still fits, which is quoted.
+NAMES_OUT_OF_RANGE = ["1e999", "123e4567", "5e1234", "-1e400", ".5e999", "0x" + "1" * 17, "0x123456789abcdef012345", "-0x8000000000000001",
+                      "+0xffffffffffffffff", "0b" + "1" * 65, "-0b" + "1" * 64, "1" * 250 + "e60", "1.7976931348623159e308",
+                      # the first 100 digits of 2^1024 - 2^970 (the midpoint above the largest double), last digit raised by one
+                      "1.79769313486231580793728971405303415079934132710037826936173778980444968292764750946649017977587208e308"]
+NAMES_STILL_IN_RANGE = ["1e308", "1.7976931348623157e308", "1.7976931348623158e308", "1e-999", "0x" + "f" * 16, "-0x8000000000000000", "+0x7fffffffffffffff",
+                        "0b" + "1" * 64, "-0b" + "1" * 63, "0b-101", "18446744073709551616", "9" * 250, "0" * 70 + "7",
+                        "1.79769313486231580793728971405303415079934132710037826936173778980444968292764750946649017977587207e308"]
 NAMES_REFUSED = ["0o17", "<<", "0x1p-2", "+0b1", "bad\xff".encode("latin-1"), b"nl\nx"]
 
 
@@ -70,6 +80,34 @@ def test_resolvable_names_are_double_quoted(built_lib, tmp_path, name):
     assert yaml.load(y.decode(), Loader=yaml.BaseLoader)["files"][0]["name"] == name
     assert _lib.parse_yaml(y)[1][0]["name"] == name
     assert yaml.safe_load(y.decode())["files"][0]["name"] == name  # quoted: even a resolving reader gets the string
+
+
+@pytest.mark.parametrize("name", NAMES_OUT_OF_RANGE + NAMES_STILL_IN_RANGE)
+def test_a_number_out_of_range_is_a_string(built_lib, oracle, tmp_path, name):
+    """strconv's range errors decide the style: out of range -> !!str -> plain; the neighbour that fits -> double-quoted.
+    Python's own float()/int() (correctly rounded, arbitrary precision) give the expected answer independently of
+    both restatements; product (exact digit compare) and oracle (strtoull/strtod) must agree with it and each other."""
+    from snappy_amd import _lib
+    tree = _tree_with(tmp_path, name)
+    y = _emit(tree)
+    plain = name.replace("_", "")
+    body = plain.lstrip("+-")
+    if body.startswith(("0x", "0X")):
+        v = int(plain, 16)
+        fits = -2**63 <= v < 2**63 or (not plain.startswith(("+", "-")) and v < 2**64)
+    elif "0b" in plain[:3]:
+        neg = plain.startswith("-0b")
+        v = int(plain[3 if neg else 2:], 2)
+        fits = -2**63 <= v < 2**63 or (not neg and not plain[2:].startswith(("+", "-")) and 0 <= v < 2**64)
+    else:
+        fits = abs(float(plain)) != float("inf")
+    assert _scalar(y) == (' "%s"' % name if fits else " " + name)
+    assert (name in NAMES_STILL_IN_RANGE) == fits
+    assert _lib.parse_yaml(y)[1][0]["name"] == name
+    tar = tmp_path / "a.tar"
+    tar.write_bytes(b"")
+    want = oracle.hashes_yaml(tree, str(tar))
+    assert y.split(b"files:\n", 1)[1] == want.split(b"files:\n", 1)[1]
 
 
 @pytest.mark.parametrize("name", NAMES_REFUSED)

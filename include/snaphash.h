@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SNAPHASH_ABI_VERSION 3
+#define SNAPHASH_ABI_VERSION 4
 
 enum {
     SNAPHASH_OK = 0,
@@ -98,16 +98,19 @@ typedef struct snaphash_config {
                                (two engines on one GPU: used by the tests on a 1-GPU box; RCCL needs distinct
                                devices, so the gather then falls back to per-device copies). */
     uint32_t n_devices;     /* 0 = the single `device` above */
-    uint32_t host_threads;  /* hybrid scheduling (host entry points only).  A lone SHA-512 stream advances at ~45 MB/s
-                               on the GPU whatever surrounds it and at ~1.4 GB/s on a host core (the library's own
-                               vectorised SHA-512, hostsha.cpp), so a stream that would set the makespan of its batch
-                               all by itself -- the package's data.tar.gz (build.go:222), a 1 GiB member -- is hashed
-                               on a host thread, concurrently with the GPU batch.
-                                 0 (default, ABI 3) = automatic: min(12, cores) threads, and ONLY streams whose own GPU
-                                     time exceeds that of the whole rest of the batch are moved;
-                                 N > 0 = N threads and the full planner: streams move while that shortens the modelled
-                                     makespan max(GPU, host);
-                                 SNAPHASH_FLAG_GPU_ONLY = none (what 0 meant in ABI 2).
+    uint32_t host_threads;  /* planning (host entry points only; planner.h, snaphash_plan_streams below).  A lone SHA-512
+                               stream advances at ~44 MB/s on the GPU whatever surrounds it and at ~1.4 GB/s on a host
+                               core (the library's own vectorised SHA-512, hostsha.cpp); a launch costs ~0.15 ms.  Every
+                               call is therefore planned: modelled GPU makespan = latency + max(longest stream / 44 MB/s,
+                               bytes / PCIe link), host makespan = LPT of the moved streams over the host threads; streams
+                               move to host threads, longest first and concurrently with the GPU batch, while that
+                               shortens max(GPU, host) -- the package's data.tar.gz (build.go:222), a 1 GiB member -- and
+                               a batch the host alone finishes sooner than any split (a lone file, a small tree dominated
+                               by one member) runs on host threads whole: no call is slower than the reference's loop.
+                                 0 (default) = as many host threads as this process may keep busy (affinity mask capped
+                                     by the cgroup CPU quota), less the staging fill threads while there is a GPU part;
+                                 N > 0 = exactly N;
+                                 SNAPHASH_FLAG_GPU_ONLY = no planning, every byte through the HIP kernels.
                                snaphash_stats_ex says which bytes went where.  Not a fallback: init still fails
                                without a gfx950 device. */
     uint32_t flags;         /* SNAPHASH_FLAG_* */
@@ -366,6 +369,54 @@ typedef struct snaphash_engine_info {
     char pci_bus_id[32];
 } snaphash_engine_info;
 int snaphash_get_engine_info(const snaphash_ctx *ctx, uint32_t i, snaphash_engine_info *out);
+
+/* ---- ABI 4: the plan of a call, host-only (no device needed) ------------------------------------------------
+ * What the planner (snaphash_config.host_threads) decides for n streams of the given lengths under a cost model;
+ * on_host[i] = 1: a host thread hashes stream i.  Zeros in the model = the library's measured MI355X defaults.
+ * The entry points plan with the ctx's own numbers (cores and host rate measured at snaphash_init). */
+typedef struct snaphash_plan_model {
+    uint32_t struct_size;    /* in: sizeof(snaphash_plan_model) */
+    uint32_t n_devices;      /* engines the GPU part is sharded over (0 = 1) */
+    uint32_t cpus;           /* host cores the call may keep busy (0 = what this process may use) */
+    uint32_t fill_threads;   /* cores one engine's staging fill occupies beside a GPU part (0 = 6 for memory, 12 for files) */
+    uint32_t host_threads;   /* 0 = automatic, N = exactly N (as snaphash_config.host_threads) */
+    uint32_t from_files;     /* sources are paths rather than caller memory */
+    double host_rate;        /* B/s, one host core's SHA-512 (0 = 1.4e9) */
+    double gpu_stream_rate;  /* B/s, ONE stream under the lane-pair kernel (0 = 44e6) */
+    double gpu_link;         /* B/s, one engine's staging + PCIe copy (0 = 54e9 memory, 48e9 files) */
+    double gpu_latency;      /* s per launch whatever its size (0 = 150e-6) */
+    /* out */
+    double gpu_seconds;      /* modelled makespan of the GPU part (0 = none) */
+    double host_seconds;     /* modelled makespan of the host part */
+    uint64_t host_streams, host_bytes;
+    uint32_t host_threads_used;
+    uint32_t reserved;
+} snaphash_plan_model;
+int snaphash_plan_streams(const uint64_t *lens, size_t n, snaphash_plan_model *model /* in/out */, uint8_t *on_host /* n, may be NULL */);
+/* CPUs this process may keep busy: affinity mask capped by the cgroup CPU quota (what host_threads = 0 plans with). */
+uint32_t snaphash_usable_cpus(void);
+/* the quota part alone, on any cgroup tree (tests): whole CPUs, 0 = none found */
+uint32_t snaphash_cgroup_cpu_quota(const char *cgroup_root, const char *proc_self_cgroup);
+
+/* ---- ABI 4: the pass with one process per GPU (SURVEY sec. 8e as torch.distributed / MPI launch it) -----------------
+ * writeHashes (build.go:216-270) over `world` ranks, each with its own ctx on its own GPU: every rank calls
+ * snaphash_shard_plan with the same tree (the walk and the LPT plan by SHA-512 block count are deterministic; the
+ * archive is stream 0, as in the Go batch shape), hashes ITS members with snaphash_shard_hash into a slab of
+ * snaphash_shard_rows() x 64 bytes (unused rows zero), the caller all-gathers the slabs in rank order (RCCL:
+ * torch.distributed.all_gather_into_tensor or ncclAllGather), and any rank turns world x rows x 64 bytes into
+ * hashes.yaml with snaphash_shard_emit (malloc'd; snaphash_free).  plan and emit need no device.  The one-process form
+ * of the same thing is snaphash_config.devices. */
+typedef struct snaphash_shard snaphash_shard;
+int snaphash_shard_plan(const char *build_dir, const char *data_tar, uint32_t rank, uint32_t world, snaphash_shard **out);
+size_t snaphash_shard_rows(const snaphash_shard *sh);     /* rows of every rank's slab */
+size_t snaphash_shard_count(const snaphash_shard *sh);    /* streams this rank hashes */
+size_t snaphash_shard_streams(const snaphash_shard *sh);  /* streams of the whole job (1 + regular files) */
+uint64_t snaphash_shard_bytes(const snaphash_shard *sh);  /* bytes this rank hashes */
+const char *snaphash_shard_path(const snaphash_shard *sh, size_t k); /* k-th stream of this rank, in slab row order */
+int snaphash_shard_hash(snaphash_ctx *ctx, snaphash_shard *sh, uint8_t *slab /* rows * 64, host */);
+int snaphash_shard_emit(const snaphash_shard *sh, const uint8_t *slabs /* world * rows * 64, rank-major */,
+                        char **yaml_out, size_t *yaml_len);
+void snaphash_shard_free(snaphash_shard *sh);
 
 /* Host-only: the topology probe the engines use, on any sysfs tree (the tests hand in a fake one).  *node = NUMA node
  * of the PCI function (-1 unknown); cpus (may be NULL) receives up to cap CPU numbers of that node, *n_cpus how many

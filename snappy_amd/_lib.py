@@ -30,6 +30,9 @@ EXPORTS = [
     "snaphash_batch_begin", "snaphash_batch_append", "snaphash_batch_end", "snaphash_batch_finish", "snaphash_batch_abort",
     "snaphash_tar_create", "snaphash_tar_create_fn", "snaphash_gzip_buffer", "snaphash_get_targz_stats",
     "snaphash_get_engine_info", "snaphash_numa_probe",
+    "snaphash_plan_streams", "snaphash_usable_cpus", "snaphash_cgroup_cpu_quota",
+    "snaphash_shard_plan", "snaphash_shard_rows", "snaphash_shard_count", "snaphash_shard_streams", "snaphash_shard_bytes",
+    "snaphash_shard_path", "snaphash_shard_hash", "snaphash_shard_emit", "snaphash_shard_free",
 ]
 FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER, FLAG_GPU_ONLY, FLAG_NO_NUMA = 1, 2, 4, 8, 16
 
@@ -53,6 +56,15 @@ class EngineInfo(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("numa_node", ctypes.c_int32),
                 ("staging_node", ctypes.c_int32), ("fill_threads", ctypes.c_uint32), ("n_cpus", ctypes.c_uint32),
                 ("pci_bus_id", ctypes.c_char * 32)]
+
+
+class PlanModel(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("n_devices", ctypes.c_uint32), ("cpus", ctypes.c_uint32),
+                ("fill_threads", ctypes.c_uint32), ("host_threads", ctypes.c_uint32), ("from_files", ctypes.c_uint32),
+                ("host_rate", ctypes.c_double), ("gpu_stream_rate", ctypes.c_double), ("gpu_link", ctypes.c_double),
+                ("gpu_latency", ctypes.c_double),
+                ("gpu_seconds", ctypes.c_double), ("host_seconds", ctypes.c_double), ("host_streams", ctypes.c_uint64),
+                ("host_bytes", ctypes.c_uint64), ("host_threads_used", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class Stats(ctypes.Structure):
@@ -156,8 +168,42 @@ def lib():
     L.snaphash_get_targz_stats.restype = None
     L.snaphash_get_engine_info.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(EngineInfo)]
     L.snaphash_numa_probe.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), vp, sz, ctypes.POINTER(sz)]
+    L.snaphash_shard_plan.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp)]
+    for f in ("rows", "count", "streams"):
+        getattr(L, "snaphash_shard_" + f).argtypes = [vp]
+        getattr(L, "snaphash_shard_" + f).restype = sz
+    L.snaphash_shard_bytes.argtypes = [vp]
+    L.snaphash_shard_bytes.restype = ctypes.c_uint64
+    L.snaphash_shard_path.argtypes = [vp, sz]
+    L.snaphash_shard_path.restype = ctypes.c_char_p
+    L.snaphash_shard_hash.argtypes = [vp, vp, vp]
+    L.snaphash_shard_emit.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.snaphash_shard_free.argtypes = [vp]
+    L.snaphash_shard_free.restype = None
+    L.snaphash_plan_streams.argtypes = [u64p, sz, ctypes.POINTER(PlanModel), vp]
+    L.snaphash_usable_cpus.argtypes = []
+    L.snaphash_usable_cpus.restype = ctypes.c_uint32
+    L.snaphash_cgroup_cpu_quota.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    L.snaphash_cgroup_cpu_quota.restype = ctypes.c_uint32
     _lib = L
     return L
+
+
+def plan_streams(lens, **model):
+    """snaphash_plan_streams: what the planner decides for streams of these lengths (host-only, no device needed).
+    Returns (on_host list of 0/1, dict of the model's outputs)."""
+    n = len(lens)
+    arr = (ctypes.c_uint64 * max(n, 1))(*[int(x) for x in lens])
+    pm = PlanModel()
+    pm.struct_size = ctypes.sizeof(PlanModel)
+    for k, v in model.items():
+        setattr(pm, k, v)
+    flags = ctypes.create_string_buffer(max(n, 1))
+    rc = lib().snaphash_plan_streams(arr, n, ctypes.byref(pm), flags)
+    if rc:
+        raise SnaphashError(rc)
+    return list(flags.raw[:n]), {"gpu_seconds": pm.gpu_seconds, "host_seconds": pm.host_seconds, "host_streams": pm.host_streams,
+                                 "host_bytes": pm.host_bytes, "host_threads": pm.host_threads_used}
 
 
 def strerror(code):

@@ -88,23 +88,30 @@ int numa_node_count(const std::string& sysfs_root)
     return n;
 }
 
-bool numa_prefer_node(int node)
+bool numa_prefer_node(int node, SavedMemPolicy* saved)
 {
-#if defined(SYS_set_mempolicy)
+#if defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
     if (node < 0 || node >= 1024) return false;
+    // what the thread had (numactl --membind / --interleave, the application's own set_mempolicy) comes back afterwards
+    saved->valid = syscall(SYS_get_mempolicy, &saved->mode, saved->mask, (unsigned long)1024 + 1, nullptr, 0ul) == 0;
     unsigned long mask[1024 / (8 * sizeof(unsigned long))] = {0};
     mask[(size_t)node / (8 * sizeof(unsigned long))] |= 1ul << ((size_t)node % (8 * sizeof(unsigned long)));
     return syscall(SYS_set_mempolicy, kMpolPreferred, mask, (unsigned long)1024 + 1) == 0;
 #else
-    (void)node;
+    (void)node; (void)saved;
     return false;
 #endif
 }
 
-void numa_default_policy()
+void numa_restore_policy(const SavedMemPolicy& saved)
 {
 #if defined(SYS_set_mempolicy)
+    if (saved.valid && saved.mode != kMpolDefault &&
+        syscall(SYS_set_mempolicy, saved.mode, saved.mask, (unsigned long)1024 + 1) == 0)
+        return;
     (void)syscall(SYS_set_mempolicy, kMpolDefault, nullptr, 0ul);
+#else
+    (void)saved;
 #endif
 }
 
@@ -120,15 +127,75 @@ int numa_node_of_address(const void* addr)
 #endif
 }
 
+// CPU quota of the cgroup(s) this process sits in, in whole CPUs (0 = none found).  A 1-GPU slice of a big host often
+// sees every CPU in its affinity mask and a CFS quota of 16: threads beyond the quota are throttled, not run.
+// cgroup v2: cpu.max = "<quota|max> <period>" in the process's group and every ancestor; v1: cpu.cfs_quota_us / _period_us.
+unsigned cgroup_cpu_quota(const std::string& sysfs_cgroup_root, const std::string& proc_self_cgroup)
+{
+    std::string text;
+    if (!read_small_file(proc_self_cgroup, text)) return 0;
+    double best = 0;
+    auto take = [&](double quota, double period) {
+        if (quota > 0 && period > 0) { const double c = quota / period; if (best == 0 || c < best) best = c; }
+    };
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        const std::string line = text.substr(pos, eol - pos);
+        pos = eol + 1;
+        const size_t c1 = line.find(':'), c2 = c1 == std::string::npos ? c1 : line.find(':', c1 + 1);
+        if (c2 == std::string::npos) continue;
+        const std::string ctrl = line.substr(c1 + 1, c2 - c1 - 1);
+        std::string path = line.substr(c2 + 1);
+        const bool v2 = ctrl.empty();
+        if (!v2) { // v1: the hierarchy that carries the "cpu" controller ("cpu", "cpu,cpuacct")
+            bool has_cpu = false;
+            for (size_t a = 0; a <= ctrl.size();) {
+                size_t b = ctrl.find(',', a);
+                if (b == std::string::npos) b = ctrl.size();
+                if (ctrl.compare(a, b - a, "cpu") == 0) has_cpu = true;
+                a = b + 1;
+            }
+            if (!has_cpu) continue;
+        }
+        const std::string base = sysfs_cgroup_root + (v2 ? "" : "/" + ctrl);
+        for (;;) { // the group and its ancestors: the tightest quota binds
+            std::string v;
+            if (v2) {
+                if (read_small_file(base + path + "/cpu.max", v) && v.compare(0, 3, "max") != 0) {
+                    char* end = nullptr;
+                    const double q = strtod(v.c_str(), &end);
+                    const double per = end ? strtod(end, nullptr) : 0;
+                    take(q, per);
+                }
+            } else {
+                std::string pv;
+                if (read_small_file(base + path + "/cpu.cfs_quota_us", v) && read_small_file(base + path + "/cpu.cfs_period_us", pv))
+                    take(strtod(v.c_str(), nullptr), strtod(pv.c_str(), nullptr));
+            }
+            if (path.empty() || path == "/") break;
+            const size_t slash = path.rfind('/');
+            path = slash == 0 || slash == std::string::npos ? "/" : path.substr(0, slash);
+        }
+    }
+    if (best <= 0) return 0;
+    return (unsigned)std::max(1.0, best + 0.5);
+}
+
 unsigned usable_cpus()
 {
+    unsigned n = 0;
     cpu_set_t set;
     CPU_ZERO(&set);
     if (sched_getaffinity(0, sizeof set, &set) == 0) {
-        const int n = CPU_COUNT(&set);
-        if (n > 0) return (unsigned)n;
+        const int c = CPU_COUNT(&set);
+        if (c > 0) n = (unsigned)c;
     }
-    return std::max(1u, std::thread::hardware_concurrency());
+    if (n == 0) n = std::max(1u, std::thread::hardware_concurrency());
+    static const unsigned quota = cgroup_cpu_quota("/sys/fs/cgroup", "/proc/self/cgroup");
+    if (quota && quota < n) n = quota;
+    return n;
 }
 
 // ---- FillPool ---------------------------------------------------------------------------------------------
@@ -157,10 +224,15 @@ void FillPool::configure(unsigned max_threads, const std::vector<int>& cpus)
 void FillPool::worker(unsigned id)
 {
     if (!cpus_.empty()) { // the whole node's CPU set, not one CPU: the kernel balances inside it
-        cpu_set_t set;
+        // ... of those the process itself may run on: a taskset / sched_setaffinity restriction the application was
+        // started with is never widened
+        cpu_set_t set, allowed;
         CPU_ZERO(&set);
-        for (int c : cpus_) if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
-        (void)sched_setaffinity(0, sizeof set, &set); // refused (cgroup cpuset without these CPUs): stay where we are
+        CPU_ZERO(&allowed);
+        const bool have_allowed = sched_getaffinity(0, sizeof allowed, &allowed) == 0;
+        for (int c : cpus_)
+            if (c >= 0 && c < CPU_SETSIZE && (!have_allowed || CPU_ISSET(c, &allowed))) CPU_SET(c, &set);
+        if (CPU_COUNT(&set) > 0) (void)sched_setaffinity(0, sizeof set, &set); // refused (cgroup cpuset without these CPUs): stay where we are
     }
     uint64_t seen = 0;
     for (;;) {

@@ -27,13 +27,39 @@ std::vector<int> parse_cpulist(const std::string& text);
 int numa_node_count(const std::string& sysfs_root);
 
 // Memory policy of the calling thread: prefer `node` for the allocations that follow (set_mempolicy MPOL_PREFERRED;
-// no libnuma: the raw system call), and back to the default.  false when the kernel refuses (no NUMA, seccomp).
-bool numa_prefer_node(int node);
-void numa_default_policy();
+// no libnuma: the raw system calls), then back to what the thread had before -- the caller's own policy (numactl,
+// set_mempolicy) is read first and restored, not reset to the default.  false when the kernel refuses
+// (no NUMA, seccomp).
+struct SavedMemPolicy {
+    bool valid = false;
+    int mode = 0;
+    unsigned long mask[1024 / (8 * sizeof(unsigned long)) + 1] = {0};
+};
+bool numa_prefer_node(int node, SavedMemPolicy* saved);
+void numa_restore_policy(const SavedMemPolicy& saved);
 // Node the page holding `addr` lives on (get_mempolicy MPOL_F_NODE | MPOL_F_ADDR), -1 when unknown.
 int numa_node_of_address(const void* addr);
-// CPUs the process may run on (sched_getaffinity): a 1-GPU slice of a big host sees its share, not the machine.
+// CPUs the process may keep busy: its affinity mask, capped by the CFS quota of its cgroup (the GPU box gives a 1-GPU
+// slice all 256 CPUs in the mask and a quota of 16: the 17th busy thread is throttled).
 unsigned usable_cpus();
+// the quota alone, on any cgroup tree (the tests hand in a fake one): whole CPUs, 0 = no quota found
+unsigned cgroup_cpu_quota(const std::string& sysfs_cgroup_root, const std::string& proc_self_cgroup);
+
+// Threads that are joined whatever path leaves the scope.  A std::thread constructor that throws (EAGAIN) halfway
+// through a pool would otherwise destroy joinable threads: std::terminate, which no catch at the C boundary can stop
+// (ADVICE r3).  The workers must end by themselves (they run to completion or watch a flag the owner sets).
+struct ThreadJoiner {
+    std::vector<std::thread> th;
+    ThreadJoiner() = default;
+    ThreadJoiner(const ThreadJoiner&) = delete;
+    ThreadJoiner& operator=(const ThreadJoiner&) = delete;
+    ~ThreadJoiner() { join_all(); }
+    void join_all()
+    {
+        for (auto& t : th)
+            if (t.joinable()) t.join();
+    }
+};
 
 // ---- a persistent pool of fill threads, pinned to a CPU set ---------------------------------------------------
 // parallel_for(n, T, fn): fn(i) for i in [0, n) on at most T of the pool's threads plus the caller; returns when

@@ -1,0 +1,113 @@
+// planner.cpp -- see planner.h.  Host-only (no HIP): the CPU suite drives it through snaphash_plan_streams.
+#include "planner.h"
+
+#include <algorithm>
+#include <functional>
+#include <queue>
+
+namespace snaphash {
+
+namespace {
+
+// as snaphash_api.cpp plan_kernels decides (the lane-pair kernel takes few, long streams; a heavy-tailed batch is cut
+// into a long head for it and a short tail for the lane-per-stream kernel)
+constexpr size_t kPairMaxStreams = 32768;
+constexpr uint64_t kPairMinBlocks = 32;
+constexpr double kThreadWorth = 250e-6; // a further host thread is started per this much host work (a start costs ~30 us)
+
+uint64_t blocks_of(uint64_t len) { return (len >> 7) + 1; }
+
+using MinHeap = std::priority_queue<double, std::vector<double>, std::greater<double>>;
+
+} // namespace
+
+PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
+{
+    PlanResult res;
+    res.on_host.assign(n, 0);
+    if (n == 0) return res;
+    const unsigned nd = std::max(1u, m.n_devices);
+    const double link = (m.gpu_link > 0 ? m.gpu_link : (m.from_files ? 48e9 : 54e9)) * nd;
+    const double g_stream = m.gpu_per_stream > 0 ? m.gpu_per_stream : (m.from_files ? 0.5e-6 : 0.15e-6);
+    const double h_stream = m.host_per_stream > 0 ? m.host_per_stream : (m.from_files ? 4e-6 : 0.05e-6);
+    const double h_rate = m.host_rate > 0 ? m.host_rate : 1.4e9;
+    const unsigned cpus = std::max(1u, m.cpus);
+    const unsigned fill = m.fill_threads * nd;
+    const unsigned h_mixed = m.host_threads ? m.host_threads : (cpus > fill ? cpus - fill : 1u); // beside a GPU part
+    const unsigned h_alone = m.host_threads ? m.host_threads : cpus;                            // no GPU part: every core hashes
+
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lens[a] > lens[b]; });
+    std::vector<double> suffix(n + 1, 0.0), suffix_blocks(n + 1, 0.0);
+    for (size_t k = n; k-- > 0;) {
+        suffix[k] = suffix[k + 1] + (double)lens[order[k]];
+        suffix_blocks[k] = suffix_blocks[k + 1] + (double)blocks_of(lens[order[k]]);
+    }
+    auto host_cost = [&](size_t k) { return (double)lens[order[k]] / h_rate + h_stream; };
+    // modelled time of the GPU part when streams order[k..] stay on it
+    auto gpu_time = [&](size_t k) {
+        if (k >= n) return 0.0;
+        const size_t left = n - k;
+        const uint64_t b0 = blocks_of(lens[order[k]]);
+        bool pair;
+        if (left <= kPairMaxStreams) pair = suffix_blocks[k] >= (double)kPairMinBlocks * (double)left;
+        else pair = b0 >= kPairMinBlocks && b0 >= 8 * blocks_of(lens[order[k + kPairMaxStreams - 1]]);
+        const double rate = pair ? m.gpu_pair_rate : m.gpu_wide_rate;
+        return m.gpu_latency + (double)left * g_stream + std::max((double)lens[order[k]] / rate, suffix[k] / link);
+    };
+
+    // the k longest streams on h_mixed host threads (LPT), the rest on the GPU: G falls and H rises with k
+    double best = gpu_time(0), best_host = 0;
+    size_t best_k = 0;
+    {
+        MinHeap pool;
+        for (unsigned t = 0; t < h_mixed; ++t) pool.push(0.0);
+        double host_makespan = 0;
+        for (size_t k = 0; k < n; ++k) {
+            const double t = pool.top() + host_cost(k);
+            pool.pop();
+            pool.push(t);
+            host_makespan = std::max(host_makespan, t);
+            const double mk = std::max(gpu_time(k + 1), host_makespan);
+            if (mk < best * 0.98) { best = mk; best_k = k + 1; best_host = host_makespan; } // move only for a real gain
+            if (host_makespan > best) break;                                               // H only grows from here
+        }
+    }
+    // no GPU part at all: the fill threads' cores hash too
+    unsigned threads = h_mixed;
+    if (h_alone > h_mixed) {
+        double work = 0;
+        for (size_t k = 0; k < n; ++k) work += host_cost(k);
+        if (std::max(work / h_alone, host_cost(0)) < best * 0.98) { // the lower bound first: the LPT pass is O(n log threads)
+            MinHeap pool;
+            for (unsigned t = 0; t < h_alone; ++t) pool.push(0.0);
+            double mk = 0;
+            for (size_t k = 0; k < n && mk < best; ++k) {
+                const double t = pool.top() + host_cost(k);
+                pool.pop();
+                pool.push(t);
+                mk = std::max(mk, t);
+            }
+            if (mk < best * 0.98) { best = mk; best_k = n; best_host = mk; threads = h_alone; }
+        }
+    }
+
+    double work = 0;
+    for (size_t k = 0; k < best_k; ++k) {
+        res.on_host[order[k]] = 1;
+        res.host_bytes += lens[order[k]];
+        work += host_cost(k);
+    }
+    res.host_streams = best_k;
+    res.gpu_seconds = gpu_time(best_k);
+    res.host_seconds = best_host;
+    if (best_k) {
+        const double want = work / kThreadWorth + 1.0;
+        res.host_threads = (unsigned)std::min<double>({(double)threads, (double)best_k, want});
+        if (res.host_threads == 0) res.host_threads = 1;
+    }
+    return res;
+}
+
+} // namespace snaphash

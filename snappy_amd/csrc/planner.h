@@ -1,0 +1,45 @@
+// planner.h -- which streams of a call the HIP kernels hash and which the library's own host SHA-512 (hostsha.cpp).
+// Internal; snaphash_plan_streams (include/snaphash.h) exposes it for the tests and for callers who want to see a plan.
+//
+// No reference counterpart: helpers.Sha512sum (helpers/helpers.go:187-201) is one goroutine.  The seam it serves is
+// that function and its loop in writeHashes (snappy/build.go:222, :241): a call through this library must never be
+// slower than the loop it replaces, and ONE SHA-512 stream advances at ~44 MB/s on MI355X (the chain is serial;
+// DESIGN.md sec. 4) against ~1.4 GB/s on a host core -- so the GPU is the right place for many streams at once and the
+// wrong one for a lone file, a tree dominated by one member, or the package's own data.tar.gz.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+namespace snaphash {
+
+struct PlanModel {
+    unsigned n_devices = 1;       // engines the GPU part is sharded over
+    unsigned cpus = 1;            // host cores the call may keep busy (affinity and cgroup quota, hostfill.h usable_cpus)
+    unsigned fill_threads = 6;    // cores ONE engine's staging fill occupies while there is a GPU part
+    unsigned host_threads = 0;    // 0 = automatic (cpus, less the fill threads while there is a GPU part); N = exactly N
+    bool from_files = false;      // sources are paths (open + pread + close per stream) rather than caller memory
+    double host_rate = 1.4e9;     // B/s of one host core's SHA-512 (measured at snaphash_init)
+    double host_per_stream = 0;   // s per stream on a host thread; 0 = 4 us for files, 0.05 us for memory
+    double gpu_pair_rate = 44e6;  // B/s of ONE stream under the lane-pair kernel (few, long streams)
+    double gpu_wide_rate = 18e6;  // B/s of ONE stream under the lane-per-stream kernel
+    double gpu_link = 0;          // B/s one engine stages and copies (PCIe inclusive); 0 = 54e9 memory, 48e9 files
+    double gpu_latency = 150e-6;  // s a launch costs whatever its size: job upload, kernel start, sync, digests back
+    double gpu_per_stream = 0;    // s per stream of planning + fill on the GPU side; 0 = 0.15 us memory, 0.5 us files
+};
+
+struct PlanResult {
+    std::vector<uint8_t> on_host; // per stream: 1 = a host thread hashes it
+    unsigned host_threads = 0;    // threads the host part should run on (0 = no host part)
+    double gpu_seconds = 0;       // modelled makespan of the GPU part (0 = no GPU part)
+    double host_seconds = 0;      // modelled makespan of the host part
+    uint64_t host_streams = 0, host_bytes = 0;
+};
+
+// Streams move to the host longest first -- the longest sets the GPU's makespan and costs the host least per byte of
+// relief -- while that shortens max(GPU, host); and the whole batch moves when the host alone beats every split (a
+// batch too small to repay a launch, or one whose longest member is most of it).
+PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m);
+
+} // namespace snaphash

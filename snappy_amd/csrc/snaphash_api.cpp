@@ -36,6 +36,7 @@
 #include "hostfill.h"
 #include "hostpass.h"
 #include "hostsha.h"
+#include "planner.h"
 #include "sha512_core.h"
 #include "sha512_kernels.h"
 #include "tarpack.h"
@@ -55,6 +56,7 @@ struct EventPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; }; // kind
 struct Slot {
     uint8_t* h_buf = nullptr; // pinned host
     uint8_t* d_buf = nullptr; // HBM
+    uint64_t cap = 0;         // bytes both hold (the engine's staging size, or less while only small jobs have come by)
     Job* h_jobs = nullptr;    // pinned
     Job* d_jobs = nullptr;
     size_t jobs_cap = 0;
@@ -151,9 +153,10 @@ struct snaphash_batch;
 
 struct snaphash_ctx {
     std::vector<std::unique_ptr<DevCtx>> dev;
-    uint32_t host_threads = 0; // threads of the hybrid scheduler (0: every byte on the GPU)
-    bool host_auto = true;     // the default: only streams that set the makespan all by themselves move
-    double host_rate = 0.40e9; // bytes/s of one host thread's SHA-512, measured at init when host_threads > 0
+    uint32_t host_threads = 0; // host threads the planner may use: 0 = automatic (the cores this process may keep busy)
+    bool gpu_only = false;     // SNAPHASH_FLAG_GPU_ONLY: no planner, every byte through the HIP kernels
+    unsigned cpus = 1;         // usable_cpus() at init: affinity mask capped by the cgroup's CPU quota
+    double host_rate = 1.4e9;  // bytes/s of one host thread's SHA-512 on this box, measured at init
     uint32_t flags = 0;
     Rccl rccl;
     std::vector<uint8_t*> d_gather; // per device: n_devices * kmax * 64 bytes
@@ -251,24 +254,32 @@ int ensure_jobs(DevCtx* c, Job** h, Job** d, size_t* cap, size_t n)
 // wherever the runtime puts it otherwise.
 hipError_t host_alloc(DevCtx* c, void** p, size_t bytes)
 {
-    if (c->numa_node >= 0 && numa_prefer_node(c->numa_node)) {
+    SavedMemPolicy saved;
+    if (c->numa_node >= 0 && numa_prefer_node(c->numa_node, &saved)) {
         const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocNumaUser);
-        numa_default_policy();
+        numa_restore_policy(saved);
         if (e == hipSuccess) return e;
         (void)hipGetLastError();
     }
     return hipHostMalloc(p, bytes, hipHostMallocDefault);
 }
 
-int ensure_slots(DevCtx* c, int nslots = 2)
+// want = 0: the engine's full staging size (every user but the hashing engine, which asks for what its job needs:
+// pinning 2 x 256 MiB costs ~40 ms, which a one-shot `snappy build` of a small tree would pay for nothing).
+int ensure_slots(DevCtx* c, int nslots = 2, uint64_t want = 0)
 {
+    if (want == 0 || want > c->staging) want = c->staging;
     for (int k = 0; k < nslots; ++k) {
         Slot& s = c->slot[k];
-        if (!s.h_buf) {
-            HIP_TRY(c, host_alloc(c, (void**)&s.h_buf, c->staging));
+        if (s.cap < want) {
+            if (s.h_buf) (void)hipHostFree(s.h_buf);
+            if (s.d_buf) (void)hipFree(s.d_buf);
+            s.h_buf = nullptr; s.d_buf = nullptr; s.cap = 0;
+            HIP_TRY(c, host_alloc(c, (void**)&s.h_buf, want));
             if (c->staging_node < 0) { s.h_buf[0] = 0; c->staging_node = numa_node_of_address(s.h_buf); }
+            HIP_TRY(c, hipMalloc((void**)&s.d_buf, want + 256)); // slack: the deflate kernel peeks 3 bytes past a chunk
+            s.cap = want;
         }
-        if (!s.d_buf) HIP_TRY(c, hipMalloc((void**)&s.d_buf, c->staging + 256)); // slack: the deflate kernel peeks 3 bytes past a chunk
         if (!s.done) HIP_TRY(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         if (!s.copied) HIP_TRY(c, hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
     }
@@ -454,7 +465,13 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     uint64_t job_bytes = 0;
     for (const Source& sc : src) job_bytes += sc.gpu_len;
     const unsigned nslots = job_bytes > 2 * c->staging ? 3u : 2u;
-    int rc = ensure_slots(c, (int)nslots);
+    // slots as large as the job needs, in powers of two from 8 MiB up to the engine's staging size (they grow when a
+    // larger job comes by, and never shrink)
+    uint64_t slot_bytes = std::min<uint64_t>(c->staging, 8u << 20);
+    while (slot_bytes < c->staging && slot_bytes < job_bytes / 2 + kAlign * n) slot_bytes <<= 1;
+    slot_bytes = std::min(slot_bytes, c->staging);
+    for (unsigned k = 0; k < nslots; ++k) slot_bytes = std::max(slot_bytes, std::min(c->slot[k].cap, c->staging)); // what is there already is used
+    int rc = ensure_slots(c, (int)nslots, slot_bytes);
     if (rc) return rc;
     rc = ensure_state(c, n, true);
     if (rc) return rc;
@@ -469,7 +486,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     std::atomic<int> first_err{0};
     std::atomic<int64_t> first_err_src{-1};
     std::vector<ReadOp> ops;
-    const uint64_t S_full = c->staging;
+    const uint64_t S_full = slot_bytes;
     unsigned batch = 0;
     double t_wait = 0, t_plan = 0, t_read = 0, t_launch = 0; // where the host side of the engine spends its time (SNAPHASH_TRACE_TREE)
 
@@ -688,18 +705,13 @@ int gather_digest_slabs(snaphash_ctx* x, const std::vector<size_t>& cnt, size_t 
     return SNAPHASH_OK;
 }
 
-// ---- hybrid scheduling (opt-in): which streams finish on host threads ---------------------
-// Rates of the two engines for ONE stream (measured on MI355X, DESIGN.md sec. 4 / profiles): the GPU
-// advances a lone stream at kGpuStreamRate whatever surrounds it, a host core at kHostRate.
-constexpr double kGpuStreamRate = 44e6;
-constexpr double kGpuAggregate = 40e9; // PCIe-inclusive rate of one device's staging engine
-constexpr uint64_t kAutoHostMinBytes = 4u << 20; // default configuration: a stream shorter than this (< 0.1 s of GPU time) never moves
+// ---- planning (planner.h): which streams the kernels take and which the library's own host SHA-512 ------
 
-// bytes per second of the library's host SHA-512 on one core of THIS box (hosts differ 3x): timed once,
-// on a 2 MiB buffer, when a ctx with host_threads > 0 is created
+// bytes per second of the library's host SHA-512 on one core of THIS box (hosts differ 3x): timed once, on a
+// 512 KiB buffer, when a ctx that may plan is created (~1 ms)
 double measure_host_rate()
 {
-    std::vector<uint8_t> buf(2u << 20, 0x5a);
+    std::vector<uint8_t> buf(512u << 10, 0x5a);
     HostSha hs;
     uint8_t out[64];
     double best = 0;
@@ -714,48 +726,16 @@ double measure_host_rate()
     return best > 50e6 ? best : 0.40e9;
 }
 
-// Streams sorted longest first; moves the longest to the host pool while that shortens the modelled
-// makespan max(GPU, host).  Returns per-stream 1 = host.
-// only_makespan_setters (the default configuration): a stream is a candidate only while it is at least
-// kAutoHostMinBytes long and its own single-stream GPU time exceeds the modelled GPU time of everything behind it
-// -- the archive next to its tree, a 1 GiB member -- so a batch of many similar streams (config 2) and every small
-// batch stay on the GPU whole.
-std::vector<uint8_t> plan_host_streams(const std::vector<Source>& src, unsigned threads, size_t ndev, double host_rate,
-                                       bool only_makespan_setters)
+PlanModel plan_model_of(const snaphash_ctx* x, bool from_files)
 {
-    const size_t n = src.size();
-    std::vector<uint8_t> on_host(n, 0);
-    if (!threads || n == 0) return on_host;
-    std::vector<uint32_t> order(n);
-    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return src[a].len > src[b].len; });
-    // prefix sums: G(k) = modelled GPU time with streams order[k..] on the GPU, H(k) = LPT makespan of
-    // order[0..k) on the host threads.  G falls and H rises with k: take the k that minimises max(G, H).
-    std::vector<double> suffix(n + 1, 0.0);
-    for (size_t k = n; k-- > 0;) suffix[k] = suffix[k + 1] + (double)src[order[k]].len;
-    auto gpu_time = [&](size_t k) {
-        if (k >= n) return 0.0;
-        return std::max((double)src[order[k]].len / kGpuStreamRate, suffix[k] / (kGpuAggregate * (double)ndev));
-    };
-    std::priority_queue<double, std::vector<double>, std::greater<double>> pool; // LPT over the host threads
-    for (unsigned t = 0; t < threads; ++t) pool.push(0.0);
-    double host_makespan = 0, best = gpu_time(0);
-    size_t best_k = 0;
-    for (size_t k = 0; k < n; ++k) {
-        if (only_makespan_setters &&
-            (src[order[k]].len < kAutoHostMinBytes ||
-             (double)src[order[k]].len / kGpuStreamRate <= suffix[k + 1] / (kGpuAggregate * (double)ndev)))
-            break;
-        const double t = pool.top() + (double)src[order[k]].len / host_rate;
-        pool.pop();
-        pool.push(t);
-        host_makespan = std::max(host_makespan, t);
-        const double m = std::max(gpu_time(k + 1), host_makespan);
-        if (m < best * 0.98) { best = m; best_k = k + 1; } // move only for a real gain
-        if (host_makespan > best) break;                   // H only grows from here
-    }
-    for (size_t k = 0; k < best_k; ++k) on_host[order[k]] = 1;
-    return on_host;
+    PlanModel m;
+    m.n_devices = (unsigned)x->dev.size();
+    m.cpus = x->cpus;
+    m.fill_threads = std::min(x->d0()->fill_cap, from_files ? 12u : 6u); // what run_reads uses per engine
+    m.host_threads = x->host_threads;
+    m.from_files = from_files;
+    m.host_rate = from_files ? x->host_rate * 0.9 : x->host_rate; // a host thread reads its file itself (pread, then hash)
+    return m;
 }
 
 // ---- one call: hybrid split, LPT shards, per-device engines, gather ------------------------
@@ -799,7 +779,15 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     if (n == 0) return SNAPHASH_OK;
     const size_t nd = x->dev.size();
     for (Source& s : src) s.gpu_len = s.len;
-    const std::vector<uint8_t> on_host = plan_host_streams(src, x->host_threads, nd, x->host_rate, x->host_auto);
+    std::vector<uint8_t> on_host(n, 0);
+    unsigned plan_threads = 0;
+    if (!x->gpu_only) {
+        std::vector<uint64_t> lens(n);
+        for (size_t i = 0; i < n; ++i) lens[i] = src[i].len;
+        PlanResult plan = plan_streams(lens.data(), n, plan_model_of(x, src[0].path != nullptr));
+        on_host.swap(plan.on_host);
+        plan_threads = plan.host_threads;
+    }
 
     // GPU part: LPT over the devices by SHA-512 block count (deterministic)
     std::vector<uint32_t> gidx;
@@ -841,7 +829,8 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     std::atomic<size_t> hnext{0};
     std::atomic<int> herr{0};
     std::atomic<int64_t> herr_src{-1};
-    std::vector<double> hbusy(x->host_threads, 0.0);
+    const unsigned nh = hidx.empty() ? 0u : std::max(1u, std::min<unsigned>(plan_threads, (unsigned)hidx.size()));
+    std::vector<double> hbusy(std::max(1u, nh), 0.0);
     std::stable_sort(hidx.begin(), hidx.end(), [&](uint32_t a, uint32_t b) { return src[a].len > src[b].len; });
     auto run_host = [&](unsigned t) {
         const double t0 = now_ms();
@@ -867,17 +856,25 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
         hbusy[t] = now_ms() - t0;
     };
 
-    std::vector<std::thread> th;
-    const unsigned nh = hidx.empty() ? 0u : std::min<unsigned>(x->host_threads, (unsigned)hidx.size());
-    for (unsigned t = 0; t < nh; ++t) th.emplace_back(run_host, t);
-    if (nd == 1) {
-        run_dev(0);
-    } else {
-        std::vector<std::thread> dth;
-        for (size_t d = 0; d < nd; ++d) dth.emplace_back(run_dev, d);
-        for (auto& t : dth) t.join();
+    // A call whose streams all went to the host has no GPU part: the calling thread is the first of the pool (the literal
+    // one-file helpers.Sha512sum starts no thread at all).  Otherwise the caller drives the engine(s).
+    const bool gpu_part = !gidx.empty();
+    ThreadJoiner th, dth;
+    try {
+        for (unsigned t = gpu_part ? 0u : 1u; t < nh; ++t) th.th.emplace_back(run_host, t);
+        if (gpu_part && nd > 1)
+            for (size_t d = 0; d < nd; ++d) dth.th.emplace_back(run_dev, d);
+    } catch (...) { // no thread to be had: end what runs (the joiners wait for it), report, hash nothing further
+        int z = 0;
+        herr.compare_exchange_strong(z, EAGAIN);
+        th.join_all();
+        dth.join_all();
+        return fail(x, SNAPHASH_ENOMEM, "could not start a worker thread");
     }
-    for (auto& t : th) t.join();
+    if (!gpu_part) { if (nh) run_host(0); }
+    else if (nd == 1) run_dev(0);
+    dth.join_all();
+    th.join_all();
 
     for (uint32_t g : hidx) { x->ex.host_bytes += src[g].len; }
     x->ex.host_streams = hidx.size();
@@ -963,10 +960,10 @@ int hash_paths(snaphash_ctx* x, const char* const* paths, size_t n, const int64_
                 src[i].len = (uint64_t)st.st_size;
             }
         };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+        ThreadJoiner th; // (an emplace_back that throws leaves through the entry point's catch; what was started is joined)
+        for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work, t);
         work(0);
-        for (auto& w : th) w.join();
+        th.join_all();
         int64_t first = -1;
         for (unsigned t = 0; t < T; ++t) if (bad[t] >= 0 && (first < 0 || bad[t] < first)) first = bad[t];
         if (first >= 0) { // an earlier path may be unreadable: the reference would have stopped there
@@ -1089,22 +1086,20 @@ try {
     if (devs.size() > 64) return init_fail(SNAPHASH_EINVAL, "more than 64 engines");
     std::unique_ptr<snaphash_ctx> x(new (std::nothrow) snaphash_ctx());
     if (!x) return SNAPHASH_ENOMEM;
-    // Hybrid scheduling (snaphash.h, snaphash_config.host_threads): automatic by default -- only streams that would
-    // set the makespan of their batch all by themselves move to a host thread; an explicit count turns the full planner
-    // on; SNAPHASH_FLAG_GPU_ONLY keeps every byte on the GPU.
+    // Planning (planner.h; snaphash.h, snaphash_config.host_threads): by default the planner may use every core this
+    // process may keep busy; an explicit count fixes it; SNAPHASH_FLAG_GPU_ONLY keeps every byte on the GPU.
     const unsigned ncpu = usable_cpus();
-    x->host_threads = std::min(12u, ncpu);
-    x->host_auto = true;
+    x->cpus = ncpu;
     if (v2) {
         x->flags = cfg->flags;
-        if (cfg->host_threads) { x->host_threads = std::min<uint32_t>(cfg->host_threads, 256); x->host_auto = false; }
+        x->host_threads = std::min<uint32_t>(cfg->host_threads, 256);
     }
-    if (!cfg && getenv("SNAPHASH_HOST_THREADS")) { // likewise for a ctx created without a config: N threads, 0 = none
+    if (!cfg && getenv("SNAPHASH_HOST_THREADS")) { // likewise for a ctx created without a config: N threads, 0 = every byte on the GPU
         x->host_threads = (uint32_t)std::min<unsigned long>(strtoul(getenv("SNAPHASH_HOST_THREADS"), nullptr, 10), 256);
-        x->host_auto = false;
+        if (x->host_threads == 0) x->flags |= SNAPHASH_FLAG_GPU_ONLY;
     }
-    if (x->flags & SNAPHASH_FLAG_GPU_ONLY) x->host_threads = 0;
-    if (x->host_threads) x->host_rate = measure_host_rate();
+    x->gpu_only = (x->flags & SNAPHASH_FLAG_GPU_ONLY) != 0;
+    if (!x->gpu_only) x->host_rate = measure_host_rate();
     // where the staging memory and its fill threads live: the GPU's own NUMA node (hostfill.h).  SNAPHASH_SYSFS_ROOT
     // points the topology probe at another tree (the tests' fake one).
     const char* sysfs_env = getenv("SNAPHASH_SYSFS_ROOT");
@@ -1443,6 +1438,143 @@ try {
 }
 
 void snaphash_free(void* p) { free(p); }
+
+// ---- ABI 4: the pass, one process per GPU (SURVEY sec. 8e in the form torch.distributed / MPI launch it) -------------
+// Every rank walks the same tree and derives the same LPT plan (deterministic, by SHA-512 block count, the archive is
+// stream 0); rank r hashes its members into a slab of `rows` digests; the caller all-gathers the slabs (RCCL); any rank
+// turns the gathered slabs into hashes.yaml.  plan and emit are host-only.
+struct snaphash_shard {
+    std::vector<Record> recs;
+    std::vector<std::string> all_paths;       // stream i of the whole job: [0] = the archive, then the regular files in walk order
+    std::vector<int64_t> all_sizes;
+    std::vector<int32_t> shard_of;            // per stream
+    std::vector<uint32_t> row_of;             // per stream: its row in its rank's slab
+    std::vector<uint32_t> mine;               // streams of this rank, in row order
+    std::vector<const char*> my_paths;
+    std::vector<int64_t> my_sizes;
+    uint32_t rank = 0, world = 1;
+    size_t rows = 1;
+    uint64_t my_bytes = 0;
+};
+
+int snaphash_shard_plan(const char* build_dir, const char* data_tar, uint32_t rank, uint32_t world, snaphash_shard** out)
+try {
+    if (!build_dir || !data_tar || !out || world == 0 || rank >= world || world > 4096) return SNAPHASH_EINVAL;
+    *out = nullptr;
+    struct stat st;
+    if (stat(data_tar, &st) != 0) return SNAPHASH_EIO; // build.go:222: a missing archive fails before the walk
+    std::unique_ptr<snaphash_shard> sh(new snaphash_shard());
+    sh->rank = rank;
+    sh->world = world;
+    int en = 0;
+    int rc = walk_tree(build_dir, sh->recs, &en);
+    if (rc) { errno = en; return rc; }
+    for (const Record& r : sh->recs)
+        if (!name_emittable(r.name)) return SNAPHASH_ENAME;
+    sh->all_paths.push_back(data_tar);
+    sh->all_sizes.push_back((int64_t)st.st_size);
+    for (const Record& r : sh->recs)
+        if (r.is_regular) { sh->all_paths.push_back(r.path); sh->all_sizes.push_back(r.size); }
+    const size_t n = sh->all_paths.size();
+    std::vector<uint64_t> lens(n);
+    for (size_t i = 0; i < n; ++i) lens[i] = (uint64_t)sh->all_sizes[i];
+    sh->shard_of.assign(n, 0);
+    if (world > 1) lpt_assign(lens.data(), n, (int)world, sh->shard_of.data());
+    std::vector<uint32_t> count(world, 0);
+    sh->row_of.resize(n);
+    for (size_t i = 0; i < n; ++i) sh->row_of[i] = count[sh->shard_of[i]]++;
+    sh->rows = 1;
+    for (uint32_t c : count) sh->rows = std::max<size_t>(sh->rows, c);
+    for (size_t i = 0; i < n; ++i)
+        if ((uint32_t)sh->shard_of[i] == rank) {
+            sh->mine.push_back((uint32_t)i);
+            sh->my_paths.push_back(sh->all_paths[i].c_str());
+            sh->my_sizes.push_back(i == 0 ? -1 : sh->all_sizes[i]); // the archive's length is taken when it is read, like snaphash_tree
+            sh->my_bytes += lens[i];
+        }
+    *out = sh.release();
+    return SNAPHASH_OK;
+} catch (...) {
+    return SNAPHASH_ENOMEM;
+}
+
+size_t snaphash_shard_rows(const snaphash_shard* sh) { return sh ? sh->rows : 0; }
+size_t snaphash_shard_count(const snaphash_shard* sh) { return sh ? sh->mine.size() : 0; }
+uint64_t snaphash_shard_bytes(const snaphash_shard* sh) { return sh ? sh->my_bytes : 0; }
+size_t snaphash_shard_streams(const snaphash_shard* sh) { return sh ? sh->all_paths.size() : 0; }
+const char* snaphash_shard_path(const snaphash_shard* sh, size_t k) { return sh && k < sh->my_paths.size() ? sh->my_paths[k] : nullptr; }
+
+int snaphash_shard_hash(snaphash_ctx* x, snaphash_shard* sh, uint8_t* slab)
+try {
+    if (!x || !sh || !slab) return fail(x, SNAPHASH_EINVAL, "bad argument");
+    TOP_ENTER(x);
+    memset(slab, 0, sh->rows * 64);
+    const int rc = hash_paths(x, sh->my_paths.data(), sh->my_paths.size(), sh->my_sizes.data(), slab, nullptr);
+    end_top(x, t_top0_);
+    return rc;
+} catch (...) {
+    return SNAPHASH_ENOMEM;
+}
+
+int snaphash_shard_emit(const snaphash_shard* sh, const uint8_t* slabs, char** yaml_out, size_t* yaml_len)
+try {
+    if (!sh || !slabs || !yaml_out) return SNAPHASH_EINVAL;
+    *yaml_out = nullptr;
+    const size_t n = sh->all_paths.size();
+    std::vector<uint8_t> dig(n * 64);
+    for (size_t i = 0; i < n; ++i)
+        memcpy(dig.data() + 64 * i, slabs + ((size_t)sh->shard_of[i] * sh->rows + sh->row_of[i]) * 64, 64);
+    std::string y;
+    const int rc = emit_yaml(sh->recs, dig.data(), dig.data() + 64, y);
+    if (rc) return rc;
+    char* p = (char*)malloc(y.size() + 1);
+    if (!p) return SNAPHASH_ENOMEM;
+    memcpy(p, y.data(), y.size());
+    p[y.size()] = 0;
+    *yaml_out = p;
+    if (yaml_len) *yaml_len = y.size();
+    return SNAPHASH_OK;
+} catch (...) {
+    return SNAPHASH_ENOMEM;
+}
+
+void snaphash_shard_free(snaphash_shard* sh) { delete sh; }
+
+// ---- ABI 4: the plan of a call (host-only) ---------------------------------------------------------------------
+int snaphash_plan_streams(const uint64_t* lens, size_t n, snaphash_plan_model* pm, uint8_t* on_host)
+try {
+    if (!pm || pm->struct_size < sizeof(snaphash_plan_model) || (n && !lens)) return SNAPHASH_EINVAL;
+    PlanModel m;
+    m.n_devices = pm->n_devices ? pm->n_devices : 1;
+    m.cpus = pm->cpus ? pm->cpus : usable_cpus();
+    m.from_files = pm->from_files != 0;
+    m.fill_threads = pm->fill_threads ? pm->fill_threads : (m.from_files ? 12u : 6u);
+    m.host_threads = pm->host_threads;
+    if (pm->host_rate > 0) m.host_rate = pm->host_rate;
+    if (pm->gpu_stream_rate > 0) m.gpu_pair_rate = pm->gpu_stream_rate;
+    if (pm->gpu_link > 0) m.gpu_link = pm->gpu_link;
+    if (pm->gpu_latency > 0) m.gpu_latency = pm->gpu_latency;
+    const PlanResult r = plan_streams(lens, n, m);
+    if (on_host && n) memcpy(on_host, r.on_host.data(), n);
+    pm->gpu_seconds = r.gpu_seconds;
+    pm->host_seconds = r.host_seconds;
+    pm->host_streams = r.host_streams;
+    pm->host_bytes = r.host_bytes;
+    pm->host_threads_used = r.host_threads;
+    return SNAPHASH_OK;
+} catch (...) {
+    return SNAPHASH_ENOMEM;
+}
+
+uint32_t snaphash_usable_cpus(void) { return usable_cpus(); }
+
+uint32_t snaphash_cgroup_cpu_quota(const char* cgroup_root, const char* proc_self_cgroup)
+try {
+    if (!cgroup_root || !proc_self_cgroup) return 0;
+    return cgroup_cpu_quota(cgroup_root, proc_self_cgroup);
+} catch (...) {
+    return 0;
+}
 
 // ---- streaming batch (row f2): bytes are fed as another pass reads them -----------------------
 
@@ -1909,10 +2041,10 @@ try {
             if (hipSetDevice(c->device) != hipSuccess) { p.rc = fail(c, SNAPHASH_EDEVICE, "hipSetDevice"); return; }
             p.rc = files_equal_impl(c, p.a.data(), p.b.data(), p.idx.size(), p.eq.data());
         };
-        std::vector<std::thread> th;
-        for (size_t d = 1; d < nd; ++d) th.emplace_back(run, d);
+        ThreadJoiner th;
+        for (size_t d = 1; d < nd; ++d) th.th.emplace_back(run, d);
         run(0);
-        for (auto& t : th) t.join();
+        th.join_all();
         for (size_t d = 0; d < nd; ++d) {
             if (part[d].rc && !rc) rc = lift(x, x->dev[d].get(), part[d].rc);
             for (size_t k = 0; k < part[d].idx.size(); ++k) equal[part[d].idx[k]] = part[d].eq[k];

@@ -1,6 +1,8 @@
 // walk.cpp -- see walk.h.
 #include "walk.h"
 
+#include "hostfill.h"
+
 #include <dirent.h>
 #include <errno.h>
 #include <string.h>
@@ -91,10 +93,10 @@ int walk_entries(const char* root_c, std::vector<WalkEntry>& ents, int* err_no, 
         }
     };
     {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+        ThreadJoiner th; // joined even when a thread cannot be started (the exception then leaves through the C entry point's catch)
+        for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work, t);
         work(0);
-        for (auto& x : th) x.join();
+        th.join_all();
     }
     int64_t first_bad = -1;
     int first_errno = 0;

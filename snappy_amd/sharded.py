@@ -45,3 +45,78 @@ def gather_digests(local_slab, plan, group=None, force_collective=False):
     dist.all_gather_into_tensor(gathered.view(-1), local_slab.contiguous().view(-1), group=group)
     index = torch.from_numpy(plan.row_of).to(local_slab.device)
     return gathered.index_select(0, index)
+
+
+class ShardedTree:
+    """writeHashes (snappy/build.go:216-270) with one process per GPU, natively (ABI 4 snaphash_shard_*): every rank
+    walks the same tree and derives the same LPT plan, hashes ITS members into a slab, ONE all-gather (RCCL on CUDA
+    tensors, gloo on CPU tensors) moves the slabs, rank 0 -- or every rank -- writes hashes.yaml.
+
+        st = ShardedTree(build_dir, data_tar, rank, world)
+        slab = st.hash(ctx)                  # this rank's digests, [rows, 64] uint8 (host)
+        yaml = st.emit(st.gather(slab))      # all ranks' slabs -> hashes.yaml
+    """
+
+    def __init__(self, build_dir, data_tar, rank, world):
+        import ctypes
+        h = ctypes.c_void_p()
+        rc = _lib.lib().snaphash_shard_plan(build_dir.encode(), data_tar.encode(), rank, world, ctypes.byref(h))
+        if rc:
+            raise _lib.SnaphashError(rc, build_dir)
+        self._h = h
+        self.rank, self.world = rank, world
+        L = _lib.lib()
+        self.rows = L.snaphash_shard_rows(h)
+        self.count = L.snaphash_shard_count(h)
+        self.streams = L.snaphash_shard_streams(h)
+        self.bytes = L.snaphash_shard_bytes(h)
+
+    def paths(self):
+        L = _lib.lib()
+        return [L.snaphash_shard_path(self._h, k).decode() for k in range(self.count)]
+
+    def hash(self, ctx, out=None):
+        """Hashes this rank's members on ctx; returns the slab as a numpy [rows, 64] uint8 array (out: reuse one)."""
+        slab = out if out is not None else np.zeros((self.rows, 64), dtype=np.uint8)
+        rc = _lib.lib().snaphash_shard_hash(ctx._h, self._h, slab.ctypes.data)
+        if rc:
+            raise _lib.SnaphashError(rc, ctx.last_error())
+        return slab
+
+    def gather(self, slab, device=None, group=None):
+        """All ranks' slabs, rank-major [world * rows, 64], on the host.  device: where the collective runs ("cuda" for
+        RCCL; None = CPU tensors over gloo)."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return slab
+        t = torch.from_numpy(slab)
+        if device is not None:
+            t = t.to(device, non_blocking=False)
+        full = torch.empty((self.world * self.rows, 64), dtype=torch.uint8, device=t.device)
+        dist.all_gather_into_tensor(full.view(-1), t.contiguous().view(-1), group=group)
+        return full.cpu().numpy()
+
+    def emit(self, slabs):
+        import ctypes
+        slabs = np.ascontiguousarray(slabs, dtype=np.uint8)
+        assert slabs.size == self.world * self.rows * 64
+        out, n = ctypes.c_void_p(), ctypes.c_size_t()
+        rc = _lib.lib().snaphash_shard_emit(self._h, slabs.ctypes.data, ctypes.byref(out), ctypes.byref(n))
+        if rc:
+            raise _lib.SnaphashError(rc)
+        try:
+            return ctypes.string_at(out, n.value)
+        finally:
+            _lib.lib().snaphash_free(out)
+
+    def close(self):
+        if self._h:
+            _lib.lib().snaphash_shard_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

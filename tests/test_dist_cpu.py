@@ -74,3 +74,68 @@ def test_plan_is_balanced_and_deterministic(built_lib):
     loads = np.array([synthetic.zipf_sizes(20000)[z.members(r)].sum() for r in range(8)], dtype=np.float64)
     # the 256 MiB head file bounds the makespan from below; LPT stays within one head file of the mean
     assert loads.max() <= max(loads.mean() + (1 << 28), 1 << 28)
+
+
+def _tree_worker(rank, world, port, build, tar, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hashlib
+        from snappy_amd.sharded import ShardedTree
+        with ShardedTree(build, tar, rank, world) as st:
+            slab = np.zeros((st.rows, 64), dtype=np.uint8)
+            for k, p in enumerate(st.paths()):  # no GPU here: this rank's digests from hashlib, into its slab rows
+                slab[k] = np.frombuffer(hashlib.sha512(open(p, "rb").read()).digest(), dtype=np.uint8)
+            y = st.emit(st.gather(slab))
+            q.put((rank, y, st.count, st.rows, st.streams, st.bytes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_tree_plan_gather_emit_gloo(world, oracle, built_lib, tmp_path):
+    """ABI 4 snaphash_shard_plan / _emit (host-only halves of the one-process-per-GPU pass): every rank walks the tree,
+    takes its LPT share, the slabs are all-gathered over gloo, and EVERY rank writes the oracle's hashes.yaml."""
+    import trees
+    rng = np.random.default_rng(8)
+    sizes = [int(x) for x in rng.integers(0, 5000, size=57)] + [0, 128, 300000, 70000, 12345]
+    build, tar = trees.make_synthetic_tree(str(tmp_path), sizes)
+    os.makedirs(os.path.join(build, "DEBIAN"))
+    open(os.path.join(build, "DEBIAN", "control"), "w").write("x")
+    os.symlink("f000001.bin", os.path.join(build, "d0000", "lnk"))
+    want = oracle.hashes_yaml(build, tar)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tree_worker, args=(r, world, port, build, tar, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(r[2] for r in res) == len(sizes) == res[0][4]  # every stream (files + the archive) has exactly one owner
+    assert max(r[2] for r in res) == res[0][3]
+    loads = [r[5] for r in res]
+    assert max(loads) - min(loads) <= 300000  # LPT: within the largest member of each other
+    for rank, y, *_ in res:
+        assert y == want, rank
+
+
+def test_sharded_tree_world_one_equals_the_plain_emitter(built_lib, oracle, tmp_path):
+    import hashlib
+    import trees
+    from snappy_amd.sharded import ShardedTree
+    build, tar = trees.make_simple_tree(str(tmp_path))
+    with ShardedTree(build, tar, 0, 1) as st:
+        slab = np.zeros((st.rows, 64), dtype=np.uint8)
+        for k, p in enumerate(st.paths()):
+            slab[k] = np.frombuffer(hashlib.sha512(open(p, "rb").read()).digest(), dtype=np.uint8)
+        assert st.emit(st.gather(slab)) == open(os.path.join(ROOT, "tests", "golden", "hashes_simple.yaml"), "rb").read()
+    from snappy_amd import _lib
+    with pytest.raises(_lib.SnaphashError):
+        ShardedTree(build, tar + ".missing", 0, 1)
+    with pytest.raises(_lib.SnaphashError):
+        ShardedTree(build, tar, 2, 2)

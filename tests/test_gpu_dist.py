@@ -67,3 +67,49 @@ def test_two_ranks_shard_hash_gather(oracle):
     assert sum(r[2] for r in res) == len(sizes)
     for rank, blob, _ in res:
         assert blob == want, rank
+
+
+def _tree_worker(rank, world, port, build, tar, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from snappy_amd import Context, _lib
+        from snappy_amd.sharded import ShardedTree
+        with Context(device=0, flags=_lib.FLAG_GPU_ONLY) as ctx, ShardedTree(build, tar, rank, world) as st:
+            slab = st.hash(ctx)
+            ex = ctx.stats_ex()
+            y = st.emit(st.gather(slab))
+        q.put((rank, y, st.count, int(ex["gpu_bytes"]), int(ex["host_bytes"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_tree_to_hashes_yaml(oracle, tmp_path):
+    """The whole pass as bench.py --gpus N times it (ABI 4 snaphash_shard_*): two ranks, each its LPT share of ONE on-disk
+    tree through the HIP kernels, slabs gathered, hashes.yaml on every rank byte-identical to the oracle's."""
+    import torch.multiprocessing as mp
+    import trees
+    rng = np.random.default_rng(21)
+    sizes = [int(x) for x in rng.integers(0, 200000, size=300)] + [0, 1, 127, 128, 129, 3 << 20, (1 << 20) + 7, 1 << 20]
+    build, tar = trees.make_synthetic_tree(str(tmp_path), sizes)
+    os.makedirs(os.path.join(build, "DEBIAN"))
+    open(os.path.join(build, "DEBIAN", "control"), "w").write("x")
+    want = oracle.hashes_yaml(build, tar)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tree_worker, args=(r, 2, port, build, tar, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=280) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(r[2] for r in res) == len(sizes)
+    assert sum(r[3] for r in res) == sum(sizes) and all(r[4] == 0 for r in res)  # every byte through the kernels
+    for rank, y, *_ in res:
+        assert y == want, rank

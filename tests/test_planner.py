@@ -1,0 +1,138 @@
+"""The planner (snappy_amd/csrc/planner.cpp, ABI 4 snaphash_plan_streams): which streams of a call the HIP kernels hash and
+which the library's own host SHA-512.  Host-only: no GPU is touched here; what the plan does on the MI355X is
+tests/test_gpu_api2.py::test_default_configuration_* and bench.py's end_to_end.breakeven leg.
+
+The seam it protects is helpers.Sha512sum and its loop in writeHashes (reference helpers/helpers.go:187-201,
+snappy/build.go:222,241): ONE goroutine at ~0.5 GB/s.  A lone SHA-512 stream advances at ~44 MB/s on the GPU, so any
+call dominated by one stream must not run there."""
+import os
+
+import pytest
+
+MiB = 1 << 20
+REF_RATE = 0.47 * 2**30  # the reference's single goroutine as the C port measures it on the GPU box (BENCH_r03 cpu_baseline)
+
+
+def _plan(lens, **kw):
+    from snappy_amd import _lib
+    kw.setdefault("cpus", 16)
+    return _lib.plan_streams(lens, **kw)
+
+
+def _makespan(r):
+    return max(r["gpu_seconds"], r["host_seconds"])
+
+
+# VERDICT r3's four breakeven shapes, and the literal one-file helpers.Sha512sum call
+BREAKEVEN = {
+    "one 256 KiB file": [256 << 10],
+    "24 files incl. one 1 MiB": [1000, 50000, 200000, 3, 4096] * 4 + [1 * MiB, 0, 77, 12345],
+    "200 files incl. one 3 MiB": [3 * MiB] + [35000] * 199,
+    "5000 x 8 KiB": [8192] * 5000,
+    "3 MiB binary in a 10 MiB snap": [3 * MiB] + [70000] * 100,
+}
+
+
+@pytest.mark.parametrize("shape", sorted(BREAKEVEN))
+@pytest.mark.parametrize("from_files", [0, 1])
+def test_no_call_is_modelled_slower_than_the_reference_loop(built_lib, shape, from_files):
+    lens = BREAKEVEN[shape]
+    on_host, r = _plan(lens, from_files=from_files)
+    serial = sum(lens) / REF_RATE + (8e-6 * len(lens) if from_files else 0)
+    assert _makespan(r) <= serial, (shape, r, serial)
+    # and the stream that would take longest on the GPU is not there
+    longest = max(range(len(lens)), key=lambda i: lens[i])
+    if lens[longest] / 44e6 > serial:
+        assert on_host[longest] == 1
+
+
+def test_the_one_file_call_starts_no_gpu_part_and_one_thread(built_lib):
+    on_host, r = _plan([256 << 10])
+    assert on_host == [1] and r["gpu_seconds"] == 0 and r["host_threads"] == 1
+    on_host, r = _plan([77])
+    assert on_host == [1] and r["host_threads"] == 1
+
+
+def test_many_similar_streams_stay_mostly_on_the_gpu(built_lib):
+    """BASELINE config 2: the GPU part is bound by its PCIe link, so the cores the staging fill leaves free take a share
+    -- and only a share: the kernels keep what the link carries."""
+    lens = [MiB] * 10001
+    on_host, r = _plan(lens)
+    assert 0 < r["host_bytes"] < 0.35 * sum(lens)
+    assert r["gpu_seconds"] < 10001 * MiB / 54e9 and abs(r["gpu_seconds"] - r["host_seconds"]) < 0.02
+    # a batch the link is NOT the bound of (1 024 x 1 MiB: the streams' own 24 ms) is left alone
+    on_host, r = _plan([MiB] * 1024)
+    assert r["host_streams"] == 0
+
+
+def test_the_archive_beside_its_tree_moves_and_nothing_else(built_lib):
+    lens = [512 * MiB] + [MiB] * 512
+    on_host, r = _plan(lens, from_files=1)
+    assert on_host[0] == 1 and sum(on_host) == 1
+    assert r["host_threads"] == 1
+
+
+def test_few_huge_streams_go_to_the_host_whole(built_lib):
+    """BASELINE config 3 (100 x 1 GiB): 100 streams x 44 MB/s = 4.4 GB/s on the GPU, 16 cores x 1.4 GB/s on the host."""
+    on_host, r = _plan([1 << 30] * 100)
+    assert sum(on_host) == 100 and r["gpu_seconds"] == 0 and r["host_threads"] == 16
+    on_host, r = _plan([1 << 30] * 100, cpus=128)
+    assert r["host_threads"] == 100  # a thread per stream at most
+
+
+def test_explicit_thread_count_and_more_cores(built_lib):
+    lens = [MiB] * 10001
+    _, r4 = _plan(lens, host_threads=4)
+    _, r32 = _plan(lens, host_threads=32)
+    assert r4["host_threads"] == 4 and r32["host_threads"] == 32 and r32["host_bytes"] > r4["host_bytes"]
+    _, one = _plan(lens, cpus=1)  # nothing to spare beside the staging fill: one thread helps a little or not at all
+    assert one["host_bytes"] < 0.05 * sum(lens)
+
+
+def test_plan_is_deterministic_and_covers_every_stream(built_lib):
+    import random
+    rng = random.Random(5)
+    lens = [rng.choice([0, 1, 127, 128, 4096, 70000, MiB, 9 * MiB]) for _ in range(3000)]
+    a, ra = _plan(lens)
+    b, rb = _plan(lens)
+    assert a == b and ra == rb and len(a) == len(lens)
+    assert ra["host_bytes"] == sum(l for l, h in zip(lens, a) if h) and ra["host_streams"] == sum(a)
+    # longest first: no stream on the GPU is longer than a stream on the host
+    gpu = [l for l, h in zip(lens, a) if not h]
+    host = [l for l, h in zip(lens, a) if h]
+    if gpu and host:
+        assert max(gpu) <= min(host)
+    assert _plan([], cpus=4)[0] == []
+
+
+def test_cgroup_cpu_quota_on_fake_trees(built_lib, tmp_path):
+    """The GPU box hands a 1-GPU job all 256 CPUs in its affinity mask and a CFS quota of 16 (profiles/r04_box_probe.txt):
+    the planner must count 16."""
+    from snappy_amd import _lib
+    L = _lib.lib()
+    # cgroup v2, quota on an ancestor
+    root = tmp_path / "v2"
+    (root / "job" / "step").mkdir(parents=True)
+    (root / "cpu.max").write_text("max 100000\n")
+    (root / "job" / "cpu.max").write_text("1600000 100000\n")
+    (root / "job" / "step" / "cpu.max").write_text("max 100000\n")
+    proc = tmp_path / "cg2"
+    proc.write_text("0::/job/step\n")
+    assert L.snaphash_cgroup_cpu_quota(str(root).encode(), str(proc).encode()) == 16
+    (root / "job" / "step" / "cpu.max").write_text("250000 100000\n")  # the tightest binds; 2.5 CPUs -> 3
+    assert L.snaphash_cgroup_cpu_quota(str(root).encode(), str(proc).encode()) == 3
+    # cgroup v1
+    root1 = tmp_path / "v1"
+    (root1 / "cpu,cpuacct" / "docker" / "abc").mkdir(parents=True)
+    (root1 / "cpu,cpuacct" / "docker" / "abc" / "cpu.cfs_quota_us").write_text("800000\n")
+    (root1 / "cpu,cpuacct" / "docker" / "abc" / "cpu.cfs_period_us").write_text("100000\n")
+    (root1 / "cpu,cpuacct" / "cpu.cfs_quota_us").write_text("-1\n")
+    (root1 / "cpu,cpuacct" / "cpu.cfs_period_us").write_text("100000\n")
+    proc1 = tmp_path / "cg1"
+    proc1.write_text("12:cpuset:/docker/abc\n4:cpu,cpuacct:/docker/abc\n0::/\n")
+    assert L.snaphash_cgroup_cpu_quota(str(root1).encode(), str(proc1).encode()) == 8
+    # none
+    proc0 = tmp_path / "cg0"
+    proc0.write_text("0::/\n")
+    assert L.snaphash_cgroup_cpu_quota(str(tmp_path / "nowhere").encode(), str(proc0).encode()) == 0
+    assert 1 <= L.snaphash_usable_cpus() <= len(os.sched_getaffinity(0))

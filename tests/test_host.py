@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert declared == set(_lib.EXPORTS)
     for s in declared:
         assert hasattr(built_lib, s), s
-    assert built_lib.snaphash_abi_version() == 3
+    assert built_lib.snaphash_abi_version() == 4
 
 
 def test_struct_layouts_match_header(built_lib):
@@ -32,6 +32,7 @@ def test_struct_layouts_match_header(built_lib):
     assert ctypes.sizeof(_lib.Stats) == 56
     assert ctypes.sizeof(_lib.Mismatch) == 8 + 4096
     assert ctypes.sizeof(_lib.Record) == 32
+    assert ctypes.sizeof(_lib.PlanModel) == 96 and _lib.PlanModel.gpu_seconds.offset == 56  # ABI 4
 
 
 def test_no_gpu_means_loud_failure(built_lib):

@@ -4,35 +4,30 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
-A step is one pass of the hot path over one batch of synthetic input: every
-file of ONE tree hashed by the HIP kernels from bytes already resident in HBM
-(snaphash_sha512_device), plus -- for N > 1 -- the RCCL all-gather of the digest
-vector.  The workload is what BASELINE.json's metric is quoted on: the
-10 000 x 1 MiB tree plus its 1 MiB archive stand-in (10 001 streams), at
-N = 1 (config 2) and LPT-sharded over N GPUs (config 4: the SAME one tree, so
-`scaling` is "strong" and the N = 1 value of a scaling run equals the plain
-N = 1 bench).  --scaling weak tiles N trees instead (labelled side experiment).
+The metric is "GiB/s hashed (whole node), bit-exact hashes.yaml" on the 10 000 x 1 MiB tree (10 001 streams with its
+1 MiB archive stand-in).  SURVEY sec. 8(d) names two timings and says which one that is:
 
-Prints ONE JSON line on rank 0:
-  value         whole-job GiB/s with inputs resident in HBM when the timed region
-                starts (value_kind says so; the PCIe- and disk-inclusive rates are
-                in `end_to_end`, they are never `value`)
-  roofline      the dominant kernel against the 8 TB/s HBM-read roofline
-                (algorithmic bytes = file bytes hashed); kernel time from HIP
-                events on the launch stream (library stats)
-  end_to_end    every N: `buffers_sharded` -- each rank hashes ITS LPT shard of the one
-                tree from host memory through snaphash_sha512_buffers (its own PCIe
-                link, staging on the GPU's NUMA node), timed between barriers, MAX over
-                ranks: the one rate of this path that shards.
-                N = 1 also: on-disk tree -> hashes.yaml (snaphash_tree, compared byte
-                for byte with the oracle's), `package` (a tree beside an archive of its
-                own size, the library's DEFAULT configuration) and `build`: Build's data
-                step fused (tar + GPU DEFLATE + archive digest + hashes.yaml) on a 1 GiB
-                text tree
-  cpu_baseline  the oracle (C restatement of the reference's serial loop) timed
-                on this box's host cores over a bounded sample of the same tree
+  (ii) END TO END -- `value`.  A step is one writeHashes pass (snappy/build.go:216-270) over ONE on-disk tree (tmpfs):
+       walk, pread into pinned staging, H2D over PCIe, the HIP kernels, hashes.yaml.  Every byte is hashed by the
+       kernels (SNAPHASH_FLAG_GPU_ONLY).  N = 1: snaphash_tree.  N > 1: the same tree, every rank its LPT share
+       (snaphash_shard_plan / _hash), ONE RCCL all-gather of the digest slabs, rank 0 writes hashes.yaml
+       (snaphash_shard_emit); `scaling` is "strong", barrier + synchronize on both sides, MAX over ranks.
+  (i)  KERNEL-RESIDENT -- `roofline` (and `hbm_resident`): the same streams already in HBM, snaphash_sha512_device; the
+       dominant kernel's algorithmic bytes over its HIP-event time against the 8 TB/s HBM-read roofline.  This rate is
+       stream-count-bound and flat in N by construction; it is reported, it is not `value`.
+
+Prints ONE JSON line on rank 0.  Beside the two above:
+  parity        hashes.yaml of the timed path byte-identical to the oracle's (N = 1) / to the single-GPU pass and a
+                hashlib sample (N > 1)
+  end_to_end    buffers_sharded (host buffers -> digests, every N); N = 1 also: tree_default (the library's DEFAULT
+                configuration: the planner may give host cores a share), package, build (rows f2 + f3, with the
+                reference-shaped and the all-cores zlib baselines), breakeven (small calls against the reference's loop)
+  configs       BASELINE configs 1, 3 and 5 on this GPU: HBM-resident GPU-only pass (roofline per config), the DEFAULT
+                configuration from host memory, the CPU port beside it, sampled parity vs hashlib
+  cpu_baseline  the oracle (C restatement of the reference's serial loop) over the same on-disk tree on one core
 """
 import argparse
+import ctypes
 import hashlib
 import json
 import os
@@ -50,6 +45,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # measured ceilings of this implementation (profiles/); refreshed per round
 VALU_SATURATED_GBPS = float(os.environ.get("SNAPHASH_VALU_CEILING_GBPS", "1215"))
+GiB = float(1 << 30)
 
 
 def parse_args():
@@ -57,29 +53,82 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C5"], help="the tree of the timed pass (BASELINE's metric: C2)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "split", "pair", "quad"])
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
-                    help="CPU work budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--e2e", default="auto", choices=["auto", "off", "buffers", "full"],
-                    help="end_to_end legs at N = 1: auto = full for C2, buffers otherwise")
-    ap.add_argument("--e2e-files", type=int, default=0, help="files of the on-disk tree leg (0 = the whole tree)")
+                    help="0 = skip the cpu_baseline leg (the oracle's serial pass over the whole tree, ~21 s for C2)")
+    ap.add_argument("--legs", default="auto", choices=["auto", "off", "full"],
+                    help="auto = every leg for the default C2 run at N = 1, buffers_sharded only otherwise")
+    ap.add_argument("--resident-steps", type=int, default=12, help="launches of the HBM-resident (roofline) pass")
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------------------------------
-# cpu_baseline: the oracle on host cores (reported baseline, not the target)
+# small helpers
+# ------------------------------------------------------------------------------------------
+def shm_dir():
+    return "/dev/shm" if os.path.isdir("/dev/shm") else None
+
+
+def bind_to_gpu_node(local_rank):
+    """The rank's source buffers and the tmpfs pages it writes belong on the socket its GPU hangs off (first touch by a
+    thread that runs there), as the engine's staging memory and fill threads are (snaphash_get_engine_info)."""
+    from snappy_amd import Context, _lib
+    try:
+        probe = Context(device=local_rank, flags=_lib.FLAG_GPU_ONLY)
+        node = probe.engine_info(0)["numa_node"]
+        probe.close()
+        if node < 0:
+            return "not bound (single NUMA node or unknown)"
+        cpus = []
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus += list(range(int(lo), int(hi or lo) + 1))
+        allowed = sorted(set(cpus) & os.sched_getaffinity(0))
+        if not allowed:
+            return "not bound (node %d has none of this process's CPUs)" % node
+        os.sched_setaffinity(0, allowed)
+        return "rank bound to NUMA node %d (%d CPUs) before it wrote its files / allocated its buffers" % (node, len(allowed))
+    except Exception as e:  # noqa: BLE001  (placement is an optimisation: never a reason to lose the line)
+        return "not bound: %r" % (e,)
+
+
+def file_index_of(path, n_files):
+    """d0012/f001234.bin -> 1234; the archive stand-in (data.tar.gz) -> n_files."""
+    base = os.path.basename(path)
+    return int(base[1:7]) if base.startswith("f") and base.endswith(".bin") else n_files
+
+
+def hashlib_check(paths, digests_hex, what):
+    for p, want in zip(paths, digests_hex):
+        h = hashlib.sha512()
+        with open(p, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 22), b""):
+                h.update(blk)
+        if h.hexdigest() != want:
+            raise SystemExit("PARITY FAILURE (%s): %s differs from hashlib.sha512" % (what, p))
+
+
+def yaml_digest_of(yaml_bytes, name):
+    """sha512 text of the record `name` in a hashes.yaml written by the library (plain names only)."""
+    key = b"- name: " + name.encode() + b"\n"
+    at = yaml_bytes.index(key)
+    line = yaml_bytes.index(b"  sha512: ", at)
+    return yaml_bytes[line + 10:line + 138].decode()
+
+
+# ------------------------------------------------------------------------------------------
+# cpu_baseline helpers: the oracle on host cores (reported baseline, not the target)
 # ------------------------------------------------------------------------------------------
 def cpu_pool_leg(sizes, seconds):
-    """The same C port on a pool of host threads (ctypes releases the GIL): what an embarrassingly
-    parallel rewrite of the reference's loop would reach.  A 1-GPU box grants ~16 CPUs whatever
-    os.cpu_count() says, so the pool is capped there; time-bounded."""
-    from oracle import oracle
+    """The same C port on a pool of host threads (ctypes releases the GIL): what an embarrassingly parallel rewrite of the
+    reference's loop would reach on the cores this job may use; time-bounded."""
     from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    from snappy_amd import _lib
     n = len(sizes)
-    cores = min(16, os.cpu_count() or 1)
-    blobs = [oracle.fill_synthetic(int(sizes[k % n]), k % n) for k in range(cores)]
+    cores = max(1, min(int(_lib.lib().snaphash_usable_cpus()), 64))
+    blobs = [oracle.fill_synthetic(int(min(sizes[k % n], 8 << 20)), k % n) for k in range(cores)]
     deadline = time.perf_counter() + seconds
 
     def work(k):
@@ -94,40 +143,77 @@ def cpu_pool_leg(sizes, seconds):
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         tot = sum(ex.map(work, range(cores)))
-    return {"value": round(tot / (time.perf_counter() - t0) / 2**30, 3), "cores": cores,
-            "note": "same C port on a %d-thread pool (the reference itself is single-goroutine)" % cores}
+    return {"value": round(tot / (time.perf_counter() - t0) / GiB, 3), "cores": cores,
+            "note": "same C port on a %d-thread pool = the cores this job may keep busy (cgroup quota; the reference itself is single-goroutine)" % cores}
 
 
-def cpu_baseline_buffers(sizes, budget_s):
-    """Files of the workload, in order, one at a time like the reference's filepath.Walk loop,
-    until ~budget_s of CPU work (content generation not timed)."""
+def cpu_port_sample(host, offsets, lens, budget_s, order=None):
+    """The oracle's Sha512sum loop, serial, over files of the workload until ~budget_s of CPU work."""
     from oracle import oracle
-    n = len(sizes)
-    done_bytes, files, t_hash, i = 0, 0, 0.0, 0
-    while t_hash < budget_s and i < n:
-        data = oracle.fill_synthetic(int(sizes[i]), i)
-        off = np.zeros(1, dtype=np.uint64)
-        ln = np.array([len(data)], dtype=np.uint64)
+    n = len(lens)
+    done_bytes, files, t_hash = 0, 0, 0.0
+    for i in (order if order is not None else range(n)):
+        if t_hash >= budget_s:
+            break
+        off = np.array([int(offsets[i])], dtype=np.uint64)
+        ln = np.array([int(lens[i])], dtype=np.uint64)
         t0 = time.perf_counter()
-        oracle.sha512_batch(data, off, ln)
+        oracle.sha512_batch(host, off, ln)
         t_hash += time.perf_counter() - t0
-        done_bytes += len(data)
+        done_bytes += int(lens[i])
         files += 1
-        i += 1
-    return {"value": round(done_bytes / t_hash / 2**30, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
-            "sample": "first %d files of the workload (%.1f MiB) through the oracle's Sha512sum loop, serial, "
-                      "%.1f s of CPU work; content generation not timed" % (files, done_bytes / 2**20, t_hash),
-            "host_cores_visible": os.cpu_count()}
+    return {"value": round(done_bytes / max(t_hash, 1e-9) / GiB, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
+            "sample": "%d file(s) of the workload (%.1f MiB) through the oracle's Sha512sum loop, serial, %.2f s of CPU work" %
+                      (files, done_bytes / 2**20, t_hash)}
 
 
 # ------------------------------------------------------------------------------------------
-# end_to_end legs (N = 1): the whole pass as a caller sees it
+# the HBM-resident pass: the roofline object of a list of streams
+# ------------------------------------------------------------------------------------------
+def resident_pass(ctx, data_ptr, offsets, lens, slab_ptr, launches, warmup):
+    """snaphash_sha512_device `launches` times after `warmup`; per-launch kernel time from HIP events on the launch stream
+    (library stats), wall time per launch beside it."""
+    for _ in range(warmup):
+        ctx.sha512_device(data_ptr, offsets, lens, slab_ptr)
+        ctx.sync()
+    k_ms, t0 = [], time.perf_counter()
+    st = None
+    for _ in range(launches):
+        ctx.sha512_device(data_ptr, offsets, lens, slab_ptr)
+        ctx.sync()
+        st = ctx.stats()
+        k_ms.append(st["kernel_ms"])
+    wall = (time.perf_counter() - t0) / max(launches, 1)
+    return float(np.mean(k_ms)), wall, st
+
+
+def roofline_of(kernel_ms, nbytes, st, workload, world, note=None):
+    from snappy_amd import _lib
+    achieved = nbytes / (kernel_ms * 1e-3) / 1e9
+    kname = _lib.KERNEL_NAMES.get(st["kernel_used"], "sha512_wide_kernel")
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % kname.replace("<", "_").replace(">", ""))
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        # PMC traffic is a per-launch figure of ONE workload: only quote it for that workload
+        if tj.get("workload", "C2") == workload and world == 1 and tj.get("bytes_per_launch", nbytes) == nbytes:
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": kname, "kernel_ms": round(kernel_ms, 4), "bytes_per_launch": int(nbytes),
+            "launches_per_pass": int(st["launches"]), "sha512_blocks_per_pass": int(st["blocks"]),
+            "frac_of_valu_ceiling": round(achieved / VALU_SATURATED_GBPS, 4),
+            "note": note or "algorithmic bytes = file bytes hashed by rank 0's launch, inputs resident in HBM; SHA-512 is "
+                            "integer-VALU and stream-count bound, not HBM bound (DESIGN.md sec. 4)"}
+
+
+# ------------------------------------------------------------------------------------------
+# end_to_end legs
 # ------------------------------------------------------------------------------------------
 def e2e_buffers_sharded(ctx, host, offsets, lens, want_digests, total_bytes, world, fence, allmax, gather):
     """Every rank: ITS shard of the one tree, host memory in, digests out (pinned staging on the GPU's NUMA node,
-    double-buffered H2D over the rank's own PCIe link, kernels).  Timed between barriers, MAX over ranks; the value is
-    the whole tree's bytes over that time.  At N = 1 this is the plain host-buffers leg."""
-    import ctypes
+    H2D over the rank's own PCIe link, kernels).  Timed between barriers, MAX over ranks; the value is the whole tree's
+    bytes over that time."""
     from snappy_amd import _lib
     n = len(lens)
     ptrs = (ctypes.c_void_p * max(n, 1))(*[host.ctypes.data + int(o) for o in offsets])
@@ -154,23 +240,45 @@ def e2e_buffers_sharded(ctx, host, offsets, lens, want_digests, total_bytes, wor
     per_rank = gather({"ms": round(mine * 1e3, 2), "h2d_ms": round(st["h2d_ms"], 2), "kernel_ms": round(st["kernel_ms"], 2),
                        "bytes": int(np.sum(lens)), "streams": n, "launches": int(st["launches"]),
                        "numa_node": info["numa_node"], "staging_node": info["staging_node"], "fill_threads": info["fill_threads"]})
-    out = {"what": "host buffers -> snaphash_sha512_buffers -> digests on the host, every rank its LPT shard of the ONE tree "
-                   "over its own PCIe link (pinned staging on the GPU's NUMA node, H2D, kernels); barrier to barrier, MAX over ranks",
-           "n_gpus": world, "ms": round(dt * 1e3, 2), "GiBps": round(total_bytes / 2**30 / dt, 2),
-           "h2d_ms": round(st["h2d_ms"], 2), "kernel_ms": round(st["kernel_ms"], 2), "launches": int(st["launches"]),
-           "per_rank": per_rank, "every_byte_on_the_gpu": True,
-           "parity": "every rank's digest vector identical to its HBM-resident pass", "best_of": 3}
-    return out
+    return {"what": "host buffers -> snaphash_sha512_buffers -> digests on the host, every rank its LPT shard of the ONE tree "
+                    "over its own PCIe link (pinned staging on the GPU's NUMA node, H2D, kernels); barrier to barrier, MAX over ranks",
+            "n_gpus": world, "ms": round(dt * 1e3, 2), "GiBps": round(total_bytes / GiB / dt, 2),
+            "h2d_ms": round(st["h2d_ms"], 2), "kernel_ms": round(st["kernel_ms"], 2), "launches": int(st["launches"]),
+            "per_rank": per_rank, "every_byte_on_the_gpu": True,
+            "parity": "every rank's digest vector identical to its HBM-resident pass", "best_of": 3}
+
+
+def e2e_tree_default(build, tar, total, want_yaml, device):
+    """The same tree through snaphash_tree in the library's DEFAULT configuration (what snaphash_init(NULL) gives a cgo
+    caller): the planner may hand the cores the staging fill leaves free a share of the streams."""
+    from snappy_amd import Context
+    with Context(device=device, flags=0) as c:
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y = c.tree(build, tar)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, c.stats(), c.stats_ex())
+        if want_yaml is not None and y != want_yaml:
+            raise SystemExit("PARITY FAILURE: default-configuration hashes.yaml differs from the GPU-only pass")
+    dt, st, ex = best
+    return {"what": "the same on-disk tree -> snaphash_tree, DEFAULT configuration (snaphash_init(NULL)): planned, the host "
+                    "cores beside the staging fill take a share (the library's own SHA-512, hostsha.cpp)",
+            "ms": round(dt * 1e3, 2), "GiBps": round(total / GiB / dt, 2), "gpu_bytes": int(ex["gpu_bytes"]),
+            "host_bytes": int(ex["host_bytes"]), "host_streams": int(ex["host_streams"]), "host_ms": round(ex["host_ms"], 1),
+            "h2d_ms": round(st["h2d_ms"], 2), "kernel_ms": round(st["kernel_ms"], 2),
+            "parity": "hashes.yaml byte-identical to the GPU-only pass (and so to the oracle's)", "best_of": 3}
 
 
 def e2e_package(total_mib=512):
     """A package as `snappy build` meets it: a tree and, beside it, an archive of the tree's own size (the stand-in
     for its data.tar.gz, snappy/build.go:222) through snaphash_tree in the library's DEFAULT configuration -- the
-    archive is ONE stream, so the default hands it to a host thread while the GPU takes the tree.  hashes.yaml is
+    archive is ONE stream, so the planner hands it to a host thread while the GPU takes the tree.  hashes.yaml is
     compared with the oracle's."""
     from oracle import oracle
     from snappy_amd import Context, synthetic
-    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    base = shm_dir()
     if base and shutil.disk_usage(base).free < (total_mib << 20) * 2 + (1 << 30):
         total_mib = max(32, int((shutil.disk_usage(base).free - (1 << 30)) // (2 << 20)))
     tmp = tempfile.mkdtemp(prefix="snaphash_pkg_", dir=base)
@@ -204,7 +312,7 @@ def e2e_package(total_mib=512):
         total = 2 * (total_mib << 20)
         return {"what": "%d x 1 MiB tree (tmpfs) + a %d MiB archive beside it -> snaphash_tree, DEFAULT configuration "
                         "(snaphash_init(NULL)): the archive, one stream, on a host thread; the tree on the GPU" % (total_mib, total_mib),
-                "bytes": total, "ms": round(dt * 1e3, 1), "GiBps": round(total / 2**30 / dt, 2),
+                "bytes": total, "ms": round(dt * 1e3, 1), "GiBps": round(total / GiB / dt, 2),
                 "gpu_bytes": int(ex["gpu_bytes"]), "host_bytes": int(ex["host_bytes"]), "host_streams": int(ex["host_streams"]),
                 "host_ms": round(ex["host_ms"], 1), "kernel_ms": round(st["kernel_ms"], 1),
                 "cpu_port_serial_ms": round(dt_c * 1e3, 1),
@@ -213,68 +321,79 @@ def e2e_package(total_mib=512):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def e2e_tree(ctx, host, offsets, lens, nfiles, cpu_seconds):
-    """on-disk tree -> hashes.yaml: walk, parallel pread, staging, H2D, kernels, YAML; the oracle's
-    serial CPU pass over the same tree is both the checker and the reference-shaped timing."""
+def e2e_breakeven():
+    """no call through the library may be slower than the loop it replaces.  Small trees on tmpfs through
+    snaphash_tree in the DEFAULT configuration against the oracle's serial pass (the reference's one goroutine) over the
+    same tree on the same box; the literal one-file helpers.Sha512sum call beside them.  All bit-exact."""
+    import random
     from oracle import oracle
-    from snappy_amd import synthetic
-    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
-    n = min(nfiles, len(lens) - 1) if nfiles else len(lens) - 1
-    need = int(np.sum(lens[:n])) + int(lens[-1])
-    if base:
-        free = shutil.disk_usage(base).free
-        if free < need + (2 << 30):
-            n = max(100, int(n * (free - (2 << 30)) / max(need, 1)))
-    tmp = tempfile.mkdtemp(prefix="snaphash_bench_", dir=base)
-    try:
-        build = os.path.join(tmp, "build")
-        os.makedirs(build)
-        made = set()
-        for i in range(n):
-            p = os.path.join(build, synthetic.file_name(i))
-            d = os.path.dirname(p)
-            if d not in made:
-                os.makedirs(d, exist_ok=True)
-                made.add(d)
-            host[int(offsets[i]):int(offsets[i]) + int(lens[i])].tofile(p)
-        tar = os.path.join(tmp, "data.tar.gz")
-        host[int(offsets[-1]):int(offsets[-1]) + int(lens[-1])].tofile(tar)
-        total = int(np.sum(lens[:n])) + int(lens[-1])
-        best = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            y_gpu = ctx.tree(build, tar)
-            dt = time.perf_counter() - t0
-            st = ctx.stats()
-            if best is None or dt < best[0]:
-                best = (dt, st)
-        t0 = time.perf_counter()
-        res = ctx.verify(build, y_gpu, tar)
-        dt_v = time.perf_counter() - t0
-        if res is not None:
-            raise SystemExit("Verify reports a mismatch on the tree just hashed: %r" % (res,))
-        out = {"what": "on-disk tree (tmpfs) -> snaphash_tree -> hashes.yaml (walk, pread, staging, H2D, kernels, YAML)",
-               "files": n + 1, "bytes": total, "ms": round(best[0] * 1e3, 2), "GiBps": round(total / 2**30 / best[0], 2),
-               "h2d_ms": round(best[1]["h2d_ms"], 2), "kernel_ms": round(best[1]["kernel_ms"], 2),
-               "verify_ms": round(dt_v * 1e3, 2), "yaml_bytes": len(y_gpu), "best_of": 3}
-        cpu = None
-        if cpu_seconds > 0:
-            t0 = time.perf_counter()
-            y_cpu = oracle.hashes_yaml(build, tar)
-            dt_c = time.perf_counter() - t0
-            if y_cpu != y_gpu:
-                raise SystemExit("PARITY FAILURE: hashes.yaml differs from the oracle's")
-            out["parity"] = "hashes.yaml byte-identical to the oracle's (%d records)" % y_gpu.count(b"- name: ")
-            cpu = {"value": round(total / 2**30 / dt_c, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
-                   "sample": "the oracle's whole writeHashes pass (walk, 32 KiB reads, SHA-512, YAML) over the same "
-                             "on-disk tree of %d files / %.0f MiB: %.1f s on one core, as the reference's single "
-                             "goroutine would run it" % (n + 1, total / 2**20, dt_c),
-                   "host_cores_visible": os.cpu_count()}
-        else:
-            out["parity"] = "not checked (--cpu-seconds 0)"
-        return out, cpu
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+    from snappy_amd import Context
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import trees
+    rng = random.Random(4)
+    shapes = [
+        ("24 files incl. one 1 MiB", [rng.randrange(100, 60000) for _ in range(23)] + [1 << 20] + [2048]),
+        ("200 files incl. one 3 MiB", [rng.randrange(1000, 70000) for _ in range(199)] + [3 << 20] + [4096]),
+        ("5000 x 8 KiB", [8192] * 5000 + [4096]),
+        ("one 256 KiB file", [256 << 10] + [512]),
+        ("3 MiB binary in a 10 MiB snap", [3 << 20] + [rng.randrange(20000, 120000) for _ in range(100)] + [4096]),
+    ]
+    rows = []
+    base = shm_dir()
+    with Context(flags=0) as c:  # ONE default ctx for all rows, as a process would hold it
+        for name, sizes in shapes:
+            tmp = tempfile.mkdtemp(prefix="snaphash_be_", dir=base)
+            try:
+                build, tar = trees.make_synthetic_tree(tmp, sizes)
+                t0 = time.perf_counter()
+                y = c.tree(build, tar)
+                first = time.perf_counter() - t0
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    y = c.tree(build, tar)
+                    ts.append(time.perf_counter() - t0)
+                ex = c.stats_ex()
+                to = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    want = oracle.hashes_yaml(build, tar)
+                    to.append(time.perf_counter() - t0)
+                if y != want:
+                    raise SystemExit("PARITY FAILURE: breakeven leg (%s): hashes.yaml differs from the oracle's" % name)
+                rows.append({"tree": name, "files": len(sizes) - 1, "bytes": int(sum(sizes)),
+                             "library_default_ms": round(min(ts) * 1e3, 3), "first_call_ms": round(first * 1e3, 3),
+                             "reference_serial_port_ms": round(min(to) * 1e3, 3),
+                             "ratio": round(min(to) / min(ts), 2), "gpu_bytes": int(ex["gpu_bytes"]), "host_bytes": int(ex["host_bytes"]),
+                             "not_slower": bool(min(ts) <= min(to))})
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        # the literal call: helpers.Sha512sum(path) as a one-element batch (INTEGRATION.md sec. 1)
+        tmp = tempfile.mkdtemp(prefix="snaphash_be_", dir=base)
+        try:
+            p = os.path.join(tmp, "one.bin")
+            blob = os.urandom(256 << 10)
+            open(p, "wb").write(blob)
+            ts, to = [], []
+            for _ in range(7):
+                t0 = time.perf_counter()
+                d = c.sha512_files([p])[0]
+                ts.append(time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                h = oracle.sha512sum(p)
+                to.append(time.perf_counter() - t0)
+            if d.hex() != h or h != hashlib.sha512(blob).hexdigest():
+                raise SystemExit("PARITY FAILURE: breakeven leg: Sha512sum of one file")
+            rows.append({"tree": "helpers.Sha512sum(one 256 KiB file), n = 1 batch", "files": 1, "bytes": 256 << 10,
+                         "library_default_ms": round(min(ts) * 1e3, 3), "first_call_ms": round(ts[0] * 1e3, 3),
+                         "reference_serial_port_ms": round(min(to) * 1e3, 3), "ratio": round(min(to) / min(ts), 2),
+                         "gpu_bytes": int(c.stats_ex()["gpu_bytes"]), "host_bytes": int(c.stats_ex()["host_bytes"]),
+                         "not_slower": bool(min(ts) <= min(to))})
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return {"what": "small trees (tmpfs) -> snaphash_tree, DEFAULT configuration, best of 5 after the first call, against the "
+                    "oracle's serial writeHashes pass over the same tree (best of 3); hashes.yaml byte-identical in every row",
+            "rows": rows, "every_row_not_slower": all(r["not_slower"] for r in rows)}
 
 
 def deflate_roofline(zs):
@@ -298,14 +417,47 @@ def deflate_roofline(zs):
             "note": "algorithmic bytes = input read + output written; bound by instruction issue and memory latency of the chain walk (DESIGN.md sec. 9)"}
 
 
-def e2e_build(ctx, total_mib=1024):
+def build_cpu_baselines(out_gz, sha_rate_gibps):
+    """What the fused build leg replaces, on this box's host cores, over the SAME tar stream (gunzipped back):
+    (a) the reference's way, one core: compress/gzip level 9 (zlib level 9 here) over a 64 MiB sample, then the two
+        SHA-512 passes it makes (archive, then every file again) at the C port's rate;
+    (b) chunk-parallel zlib level 6 (1 MiB chunks, independent, pigz-style) on every core this job may keep busy."""
+    import gzip
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    from snappy_amd import _lib
+    tar = gzip.decompress(open(out_gz, "rb").read())
+    sample = tar[:64 << 20]
+    t0 = time.perf_counter()
+    z9 = zlib.compress(sample, 9)
+    dt9 = time.perf_counter() - t0
+    rate9 = len(sample) / dt9                                  # B/s of tar stream, one core
+    ratio9 = len(z9) / len(sample)
+    sha_rate = sha_rate_gibps * GiB
+    per_byte = 1.0 / rate9 + ratio9 / sha_rate + 1.0 / sha_rate  # compress + hash the archive + hash every file again
+    cores = max(1, int(_lib.lib().snaphash_usable_cpus()))
+    chunks = [tar[i:i + (1 << 20)] for i in range(0, len(tar), 1 << 20)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        outs = list(ex.map(lambda b: len(zlib.compress(b, 6)), chunks))
+    dt6 = time.perf_counter() - t0
+    return {"reference_way_one_core": {"GiBps_of_tree": round(1.0 / per_byte / GiB, 4), "cores": 1, "zlib9_MBps": round(rate9 / 1e6, 1),
+                                       "ratio": round(ratio9, 4),
+                                       "sample": "zlib level 9 over the first 64 MiB of the same tar stream (%.1f s) + two SHA-512 passes "
+                                                 "at the C port's %.3f GiB/s (clickdeb/deb.go:271, snappy/build.go:222,241)" % (dt9, sha_rate_gibps)},
+            "chunk_parallel_zlib6_all_cores": {"GiBps_of_tree": round(len(tar) / dt6 / GiB, 3), "cores": cores, "ratio": round(sum(outs) / len(tar), 4),
+                                               "sample": "the whole tar stream (%d MiB) in independent 1 MiB chunks, zlib level 6, %d threads "
+                                                         "(compression only: no SHA-512, no file I/O)" % (len(tar) >> 20, cores)}}
+
+
+def e2e_build(ctx, sha_rate_gibps, total_mib=1024):
     """Rows f2 + f3: `Build`'s data step in one pass -- data.tar.gz (GPU DEFLATE) + archive digest + per-file SHA-512
     + hashes.yaml, every file read once -- on a compressible tree (Zipf-word text, 1 MiB files); the archive is read
     back with tarfile and the yaml compared with the oracle's over the tree and the archive just written."""
     import tarfile
     from oracle import oracle
     from snappy_amd import synthetic
-    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    base = shm_dir()
     if base and shutil.disk_usage(base).free < (total_mib << 20) * 2 + (1 << 30):
         total_mib = max(64, int((shutil.disk_usage(base).free - (1 << 30)) // (2 << 20)))  # the tree and its archive must fit
     tmp = tempfile.mkdtemp(prefix="snaphash_build_", dir=base)
@@ -338,19 +490,117 @@ def e2e_build(ctx, total_mib=1024):
                 break
             if m.isreg() and tf.extractfile(m).read() != open(os.path.join(build, m.name[2:]), "rb").read():
                 raise SystemExit("PARITY FAILURE: archive member %s differs from the file" % m.name)
-        return {"what": "on-disk tree (tmpfs, %d x 1 MiB Zipf-word text) -> snaphash_tar_create: tar + GPU DEFLATE + archive "
-                        "SHA-512 + per-file SHA-512 + hashes.yaml, one read of every file" % total_mib,
-                "tar_bytes": int(zs["tar_bytes"]), "gz_bytes": int(zs["gz_bytes"]), "ratio": round(zs["gz_bytes"] / zs["tar_bytes"], 4),
-                "ms": round(dt * 1e3, 1), "GiBps_of_tree": round(zs["tar_bytes"] / 2**30 / dt, 2),
-                "deflate_kernel_ms": round(zs["deflate_ms"], 1), "sha512_kernel_ms": round(st["kernel_ms"], 1),
-                "deflate_kernel": deflate_roofline(zs),
-                "bound": "the DEFLATE kernel, with the serial SHA-512 of the archive on one host core close behind (DESIGN.md sec. 9)",
-                "parity": "archive inflates to the tree (tarfile); archive digest = hashlib; hashes.yaml byte-identical to the oracle's",
-                "best_of": 3}
+        res = {"what": "on-disk tree (tmpfs, %d x 1 MiB Zipf-word text) -> snaphash_tar_create: tar + GPU DEFLATE + archive "
+                       "SHA-512 + per-file SHA-512 + hashes.yaml, one read of every file" % total_mib,
+               "tar_bytes": int(zs["tar_bytes"]), "gz_bytes": int(zs["gz_bytes"]), "ratio": round(zs["gz_bytes"] / zs["tar_bytes"], 4),
+               "ms": round(dt * 1e3, 1), "GiBps_of_tree": round(zs["tar_bytes"] / GiB / dt, 2),
+               "deflate_kernel_ms": round(zs["deflate_ms"], 1), "sha512_kernel_ms": round(st["kernel_ms"], 1),
+               "deflate_kernel": deflate_roofline(zs),
+               "bound": "the DEFLATE kernel, with the serial SHA-512 of the archive on one host core close behind (DESIGN.md sec. 9)",
+               "parity": "archive inflates to the tree (tarfile); archive digest = hashlib; hashes.yaml byte-identical to the oracle's",
+               "best_of": 3}
+        try:
+            res["cpu_baseline"] = build_cpu_baselines(out, sha_rate_gibps)
+        except Exception as e:  # noqa: BLE001
+            res["cpu_baseline"] = {"error": repr(e)[:200]}
+        return res
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+# ------------------------------------------------------------------------------------------
+# BASELINE configs 1, 3, 5 on one GPU
+# ------------------------------------------------------------------------------------------
+def config_leg(name, device, kern, cpu_budget_s):
+    """HBM-resident GPU-only pass (roofline), then the DEFAULT configuration from host memory, the CPU port beside it,
+    sampled parity vs hashlib."""
+    import torch
+    from snappy_amd import Context, _lib, synthetic
+    sizes = synthetic.config_sizes(name)
+    n = len(sizes)
+    total = int(sizes.sum())
+    note = None
+    free_host = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) * 1024
+    cg = "/sys/fs/cgroup/memory.max"
+    if os.path.exists(cg):
+        lim = open(cg).read().strip()
+        if lim.isdigit():
+            free_host = min(free_host, int(lim))
+    free_hbm = torch.cuda.mem_get_info()[0]
+    if total + (8 << 30) > min(free_hbm, free_host - (24 << 30)):  # C3 needs 100 GiB of HBM and of host memory
+        fit = max(1, int((min(free_hbm, free_host - (24 << 30)) - (8 << 30)) // int(sizes.max())))
+        sizes = sizes[:min(n, fit)]
+        note = "scaled to %d of %d streams: %d GiB of HBM / %d GiB of host memory free" % (len(sizes), n, free_hbm >> 30, free_host >> 30)
+        n, total = len(sizes), int(sizes.sum())
+    offsets, packed = synthetic.pack_offsets(sizes)
+    findex = np.arange(n, dtype=np.uint64)
+    out = {"streams": n, "bytes": total}
+    if note:
+        out["scaled"] = note
+    rctx = Context(device=device, kernel=kern, stream=torch.cuda.current_stream().cuda_stream, flags=_lib.FLAG_GPU_ONLY)
+    data = torch.empty(max(packed, 16), dtype=torch.uint8, device="cuda")
+    rctx.fill_synthetic_device(data.data_ptr(), offsets, sizes, findex)
+    slab = torch.zeros((n, 64), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    heavy = total / 44e6 / max(n, 1) > 1.0 or float(sizes.max()) / 44e6 > 2.0  # a pass of many seconds: one launch, no warm-up
+    k_ms, wall, st = resident_pass(rctx, data.data_ptr(), offsets, sizes, slab.data_ptr(), 1 if heavy else 5, 0 if heavy else 1)
+    want = slab.cpu().numpy()
+    out["hbm_resident"] = {"ms": round(wall * 1e3, 3), "GiBps": round(total / GiB / wall, 3), "launches_timed": 1 if heavy else 5,
+                           "roofline": roofline_of(k_ms, total, st, name, 1)}
+    rctx.close()
+    host = data.cpu().numpy()
+    del data, slab
+    torch.cuda.empty_cache()
+    # sampled parity vs hashlib (OpenSSL), independent of both the library and the oracle
+    rng = np.random.default_rng(3)
+    sample = sorted(set([0, n - 1, int(np.argmax(sizes)), int(np.argmin(sizes))] + [int(x) for x in rng.integers(0, n, size=8)]))
+    budget = 3 << 30
+    checked = 0
+    for i in sample:
+        if budget < int(sizes[i]) and checked >= 2:
+            continue
+        budget -= int(sizes[i])
+        if hashlib.sha512(host[int(offsets[i]):int(offsets[i]) + int(sizes[i])]).digest() != want[i].tobytes():
+            raise SystemExit("PARITY FAILURE: config %s stream %d differs from hashlib.sha512" % (name, i))
+        checked += 1
+    out["parity"] = "%d sampled streams bit-exact vs hashlib.sha512; default-configuration vector identical to the GPU-only one" % checked
+    # the DEFAULT configuration from host memory
+    ptrs = (ctypes.c_void_p * n)(*[host.ctypes.data + int(o) for o in offsets])
+    clens = (ctypes.c_uint64 * n)(*[int(x) for x in sizes])
+    dig = ctypes.create_string_buffer(64 * n)
+    with Context(device=device, flags=0) as c:
+        best = None
+        for _ in range(2 if total > (16 << 30) else 3):
+            t0 = time.perf_counter()
+            rc = _lib.lib().snaphash_sha512_buffers(c._h, ptrs, clens, n, dig)
+            dt = time.perf_counter() - t0
+            if rc:
+                raise SystemExit("snaphash_sha512_buffers failed on config %s: %d" % (name, rc))
+            if best is None or dt < best[0]:
+                best = (dt, c.stats(), c.stats_ex())
+        cpus = int(_lib.lib().snaphash_usable_cpus())
+    if not np.array_equal(np.frombuffer(dig.raw, dtype=np.uint8).reshape(n, 64), want):
+        raise SystemExit("PARITY FAILURE: config %s: default-configuration digests differ from the GPU-only pass" % name)
+    dt, st, ex = best
+    out["default_config"] = {"what": "host buffers -> snaphash_sha512_buffers, DEFAULT configuration (planned: planner.h)",
+                             "ms": round(dt * 1e3, 2), "GiBps": round(total / GiB / dt, 2), "gpu_bytes": int(ex["gpu_bytes"]),
+                             "host_bytes": int(ex["host_bytes"]), "host_streams": int(ex["host_streams"]), "host_ms": round(ex["host_ms"], 1),
+                             "kernel_ms": round(st["kernel_ms"], 2), "h2d_ms": round(st["h2d_ms"], 2), "usable_cpus": cpus}
+    order = list(np.argsort(-sizes.astype(np.int64))[:1]) + [int(x) for x in rng.permutation(n)[:4000]] if name == "C5" else None
+    out["cpu_port"] = cpu_port_sample(host, offsets, sizes, cpu_budget_s, order)
+    if name == "C5":
+        head = float(sizes.max())
+        out["note"] = ("bound by its %d MiB head: ONE stream, %.2f s on one host core at the measured host rate and %.1f s on the GPU; "
+                       "no number of GPUs shortens it, so C5 cannot scale with N (DESIGN.md sec. 6)" %
+                       (int(head) >> 20, head / 1.4e9, head / 44e6))
+    if name == "C3":
+        out["note"] = ("100 streams x 44 MB/s = 4.4 GB/s is all the GPU can do for 100 SHA-512 chains; the planner gives every "
+                       "stream to a host thread (%d usable cores here), the GPU hashes 0 bytes in the default configuration" % cpus)
+    del host
+    return out
+
+
+# ------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     # stdout carries ONE JSON line and nothing else: whatever the libraries below print there (RCCL's version banner
@@ -358,10 +608,11 @@ def main():
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    t_start = time.perf_counter()
     import torch
     import torch.distributed as dist
     from snappy_amd import Context, _lib, synthetic
-    from snappy_amd.sharded import ShardPlan, gather_digests
+    from snappy_amd.sharded import ShardedTree
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -371,232 +622,273 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)
-    # SNAPHASH_BENCH_FORCE_DIST=1: run the RCCL path even with one rank (rehearsal on a 1-GPU box)
+    # SNAPHASH_BENCH_SAME_GPU=1: every rank on GPU 0, control plane and digest gather over gloo (RCCL refuses two ranks on
+    # one device): how a 1-GPU box rehearses the N > 1 path.  SNAPHASH_BENCH_FORCE_DIST=1: the RCCL path with one rank.
+    same_gpu = os.environ.get("SNAPHASH_BENCH_SAME_GPU") == "1"
+    device = 0 if same_gpu else local_rank
+    torch.cuda.set_device(device)
     force_dist = os.environ.get("SNAPHASH_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
     use_dist = world > 1 or force_dist
+    coll_device = None if same_gpu else "cuda"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    kern = {"auto": _lib.KERNEL_AUTO, "wide": _lib.KERNEL_WIDE, "split": _lib.KERNEL_SPLIT, "pair": _lib.KERNEL_PAIR,
-            "quad": getattr(_lib, "KERNEL_QUAD", 4)}[args.kernel]
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = Context(device=local_rank, kernel=kern, stream=stream)
-    tree = synthetic.config_sizes(args.workload)
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_job(sizes, steps, warmup):
-        """One file list LPT-sharded over the ranks; returns timing + the gathered digest matrix."""
-        findex = np.arange(len(sizes), dtype=np.uint64)
-        plan = ShardPlan(sizes, world)
-        mine = plan.members(rank)
-        my_lens = np.ascontiguousarray(sizes[mine])
+    def allmax(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_device or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_obj(obj):
+        if not use_dist:
+            return [obj]
+        objs = [None] * world
+        dist.all_gather_object(objs, obj)
+        return objs
+
+    def bcast_obj(obj):
+        if not use_dist:
+            return obj
+        box = [obj]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    kern = {"auto": _lib.KERNEL_AUTO, "wide": _lib.KERNEL_WIDE, "split": _lib.KERNEL_SPLIT, "pair": _lib.KERNEL_PAIR,
+            "quad": getattr(_lib, "KERNEL_QUAD", 4)}[args.kernel]
+    numa_note = bind_to_gpu_node(device)
+    sizes = synthetic.config_sizes(args.workload)
+    n_files = len(sizes) - 1           # the last size is the archive stand-in
+    total_bytes = int(sizes.sum())
+
+    # ---- the ONE on-disk tree (tmpfs).  Rank 0 lays out directories and empty files of the right size; every rank then
+    # plans (the walk sees the sizes) and writes the content of ITS members, so their page-cache pages sit on its socket.
+    base = shm_dir()
+    tmp = None
+    if rank == 0:
+        need = total_bytes + (4 << 30)
+        if base and shutil.disk_usage(base).free < need:
+            raise SystemExit("not enough room in %s for the %d MiB tree" % (base, total_bytes >> 20))
+        tmp = tempfile.mkdtemp(prefix="snaphash_bench_", dir=base)
+        build0 = os.path.join(tmp, "build")
+        os.makedirs(build0)
+        made = set()
+        for i in range(n_files):
+            p = os.path.join(build0, synthetic.file_name(i))
+            d = os.path.dirname(p)
+            if d not in made:
+                os.makedirs(d, exist_ok=True)
+                made.add(d)
+            with open(p, "wb") as f:
+                f.truncate(int(sizes[i]))
+        with open(os.path.join(tmp, "data.tar.gz"), "wb") as f:
+            f.truncate(int(sizes[n_files]))
+    tmp = bcast_obj(tmp)
+    build, tar = os.path.join(tmp, "build"), os.path.join(tmp, "data.tar.gz")
+    line = None
+    try:
+        if use_dist:
+            dist.barrier()
+        rstream = torch.cuda.current_stream().cuda_stream
+        rctx = Context(device=device, kernel=kern, stream=rstream, flags=_lib.FLAG_GPU_ONLY)  # the resident (roofline) pass: torch's stream
+        ectx = Context(device=device, kernel=kern, flags=_lib.FLAG_GPU_ONLY)                    # the timed pass: own stream, own staging
+        plan = ShardedTree(build, tar, rank, world)
+        my_paths = plan.paths()
+        my_index = np.array([file_index_of(p, n_files) for p in my_paths], dtype=np.uint64)
+        my_lens = np.ascontiguousarray(sizes[my_index.astype(np.int64)]) if len(my_paths) else np.zeros(0, dtype=np.uint64)
         my_off, my_total = synthetic.pack_offsets(my_lens)
         data = torch.empty(max(my_total, 16), dtype=torch.uint8, device="cuda")
-        ctx.fill_synthetic_device(data.data_ptr(), my_off, my_lens, np.ascontiguousarray(findex[mine]))
-        local = torch.zeros((max(plan.kmax, 1), 64), dtype=torch.uint8, device="cuda")
+        rctx.fill_synthetic_device(data.data_ptr(), my_off, my_lens, my_index)
         torch.cuda.synchronize()
-        kernel_ms = []
-        full = None
+        host = data.cpu().numpy()  # the same bytes in this rank's host memory: written to its files, and the source of the buffers leg
+        for k, p in enumerate(my_paths):
+            host[int(my_off[k]):int(my_off[k]) + int(my_lens[k])].tofile(p)
 
-        def step(record):
-            ctx.sha512_device(data.data_ptr(), my_off, my_lens, local.data_ptr())
-            out = gather_digests(local, plan, force_collective=force_dist)  # RCCL all-gather of the slabs (no-op at N = 1)
-            ctx.sync()
-            if record:
-                kernel_ms.append(ctx.stats()["kernel_ms"])
-            return out
-        for _ in range(warmup):
-            step(False)
+        # ---- (i) kernel-resident: this rank's streams already in HBM -> roofline ---------------------------------
+        slab = torch.zeros((max(plan.rows, 1), 64), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        k_ms, r_wall, r_st = resident_pass(rctx, data.data_ptr(), my_off, my_lens, slab.data_ptr(), args.resident_steps, 3)
+        my_want = slab[:len(my_paths)].cpu().numpy()
+        r_wall = allmax(r_wall)
+        del data
+        torch.cuda.empty_cache()
+
+        # ---- (ii) end to end: the timed region ---------------------------------------------------------------------
+        last = {}
+
+        def step():
+            if world == 1 and not force_dist:
+                last["yaml"] = ectx.tree(build, tar)
+                return
+            with ShardedTree(build, tar, rank, world) as st:
+                mine = st.hash(ectx)
+                slabs = st.gather(mine, device=coll_device)
+                if rank == 0:
+                    last["yaml"] = st.emit(slabs)
+        for _ in range(args.warmup):
+            step()
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            full = step(True)
+        for _ in range(args.steps):
+            step()
         fence()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return {"elapsed": elapsed, "kernel_ms": float(np.mean(kernel_ms)), "my_bytes": int(my_lens.sum()),
-                "my_streams": len(my_lens), "digests": full.cpu().numpy(), "stats": ctx.stats(),
-                "data": data, "my_off": my_off, "my_lens": my_lens, "total_bytes": int(sizes.sum())}
+        elapsed = allmax(time.perf_counter() - t0)
+        e_st = ectx.stats()
+        per_rank_step = gather_obj({"streams": len(my_paths), "bytes": int(my_lens.sum()), "h2d_ms": round(e_st["h2d_ms"], 2),
+                                    "kernel_ms": round(e_st["kernel_ms"], 2), "launches": int(e_st["launches"])})
+        ms_step = elapsed / args.steps * 1e3
+        value = total_bytes / GiB / (elapsed / args.steps)
 
-    ntrees = world if args.scaling == "weak" else 1
-    sizes = np.tile(tree, ntrees)
-    job = run_job(sizes, args.steps, args.warmup)
+        # ---- parity of the timed path, outside the timed region ----------------------------------------------------
+        parity, cpu, oracle_yaml = None, None, None
+        full_legs = rank == 0 and world == 1 and not force_dist and (args.legs == "full" or (args.legs == "auto" and args.workload == "C2"))
+        if rank == 0:
+            y = last["yaml"]
+            rng = np.random.default_rng(1)
+            sample = sorted(set([0, n_files - 1] + [int(x) for x in rng.integers(0, n_files, size=14)]))
+            names = [synthetic.file_name(i) for i in sample]
+            hashlib_check([os.path.join(build, nm) for nm in names], [yaml_digest_of(y, nm) for nm in names], "timed path")
+            parity = {"hashlib_sample": "%d files of the timed pass's hashes.yaml bit-exact vs hashlib.sha512" % len(sample),
+                      "yaml_bytes": len(y), "records": y.count(b"- name: "), "sha512_of_yaml": hashlib.sha512(y).hexdigest()[:32]}
+            if world > 1 or force_dist:  # the sharded YAML against the single-GPU pass over the same tree
+                y1 = ectx.tree(build, tar)
+                if y1 != y:
+                    raise SystemExit("PARITY FAILURE: the sharded pass's hashes.yaml differs from the single-GPU snaphash_tree's")
+                parity["result"] = "hashes.yaml of the %d-rank pass byte-identical to the single-GPU snaphash_tree's" % world
+            if args.cpu_seconds > 0 and (world == 1 and not force_dist):
+                from oracle import oracle
+                t0 = time.perf_counter()
+                oracle_yaml = oracle.hashes_yaml(build, tar)
+                dt_c = time.perf_counter() - t0
+                if oracle_yaml != y:
+                    raise SystemExit("PARITY FAILURE: hashes.yaml differs from the oracle's")
+                parity["result"] = "hashes.yaml byte-identical to the oracle's (%d records)" % y.count(b"- name: ")
+                cpu = {"value": round(total_bytes / GiB / dt_c, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
+                       "sample": "the oracle's whole writeHashes pass (walk, 32 KiB reads, SHA-512, YAML) over the same on-disk "
+                                 "tree of %d files / %.0f MiB: %.1f s on one core, as the reference's single goroutine would run it" %
+                                 (n_files + 1, total_bytes / 2**20, dt_c),
+                       "host_cores_visible": os.cpu_count(), "usable_cpus": int(_lib.lib().snaphash_usable_cpus())}
+                cpu["all_cores"] = cpu_pool_leg(sizes, 3.0)
+            elif "result" not in parity:
+                parity["result"] = "hashlib sample only (--cpu-seconds 0)"
 
-    # the other reading of "scaling" beside the headline, on record (N > 1 only)
-    side_leg = None
-    if use_dist:
-        other = "weak" if args.scaling == "strong" else "strong"
-        osizes = np.tile(tree, world if other == "weak" else 1)
-        nrep = max(3, min(10, args.steps))
-        j2 = run_job(osizes, nrep, 2)
-        side_leg = {"scaling": other,
-                    "workload": "%d %s tree(s) (%d files) LPT-sharded over %d GPU(s) + RCCL digest all-gather" %
-                                (world if other == "weak" else 1, args.workload, len(osizes), world),
-                    "value": round(j2["total_bytes"] / 2**30 / (j2["elapsed"] / nrep), 3), "unit": "GiB/s",
-                    "ms_per_step": round(j2["elapsed"] / nrep * 1e3, 4), "steps": nrep}
-        del j2
+        # ---- end_to_end legs ------------------------------------------------------------------------------------------
+        end_to_end, configs = {}, None
 
-    # ---- parity spot check of the timed path, outside the timed region ------------------
-    digests = job["digests"]
-    parity = None
-    if rank == 0:
-        rng = np.random.default_rng(1)
-        sample = sorted(set([0, len(sizes) - 1] + [int(x) for x in rng.integers(0, len(sizes), size=14)]))
-        sample = [i for i in sample if sizes[i] <= (64 << 20)] or [int(np.argmin(sizes))]
-        for i in sample:  # independent check: numpy generator + hashlib (OpenSSL), not the timed path
-            want = hashlib.sha512(synthetic.file_bytes(int(sizes[i]), int(i))).digest()
-            if digests[i].tobytes() != want:
-                raise SystemExit("PARITY FAILURE: file %d digest differs from hashlib.sha512" % i)
-        parity = {"checked_files": len(sample), "result": "bit-exact vs hashlib.sha512",
-                  "sha512_of_digest_vector": hashlib.sha512(digests.tobytes()).hexdigest()[:32]}
-
-    # ---- end-to-end legs ------------------------------------------------------------------
-    # every N: each rank hashes its shard from host memory over its own PCIe link (the rate that shards);
-    # N = 1 also: on-disk tree, package (default configuration), fused build; and the CPU baseline.
-    end_to_end, cpu = None, None
-    mode = args.e2e
-    if mode == "auto":
-        mode = "full" if args.workload == "C2" else ("buffers" if job["total_bytes"] <= (16 << 30) else "off")
-    if force_dist and world == 1 and mode == "full":
-        mode = "buffers"
-    if mode != "off":
-        # The source buffers belong on the socket this rank's GPU hangs off (first touch by a thread that runs there), as the
-        # engine's staging memory and fill threads are (snaphash_get_engine_info): eight ranks' copies then stay on
-        # their own memory controllers instead of crossing the socket link.
-        numa_note = "not bound"
-        try:
-            probe = Context(device=local_rank, flags=_lib.FLAG_GPU_ONLY)
-            node = probe.engine_info(0)["numa_node"]
-            probe.close()
-            if node >= 0:
-                cpus = []
-                for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
-                    lo, _, hi = part.partition("-")
-                    cpus += list(range(int(lo), int(hi or lo) + 1))
-                allowed = sorted(set(cpus) & os.sched_getaffinity(0))
-                if allowed:
-                    os.sched_setaffinity(0, allowed)
-                    numa_note = "rank bound to NUMA node %d (%d CPUs) before its source buffers were allocated" % (node, len(allowed))
-        except Exception as e:  # noqa: BLE001  (placement is an optimisation: never a reason to lose the line)
-            numa_note = "not bound: %r" % (e,)
-        host = job["data"].cpu().numpy()  # the same bytes the resident pass hashed, now in this rank's host memory
-        del job["data"]
-        torch.cuda.empty_cache()
-        ectx = Context(device=local_rank, kernel=kern, flags=_lib.FLAG_GPU_ONLY)  # own stream and staging engine
-        end_to_end = {}
-
-        def allmax(x):
-            if not use_dist:
-                return x
-            t = torch.tensor([x], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
-
-        def gather(obj):
-            if not use_dist:
-                return [obj]
-            objs = [None] * world
-            dist.all_gather_object(objs, obj)
-            return objs
-        mine = ShardPlan(sizes, world).members(rank)
-        local_want = digests[mine] if len(mine) else digests[:0]
-        r = e2e_buffers_sharded(ectx, host, job["my_off"], job["my_lens"], local_want, job["total_bytes"], world, fence, allmax, gather)
-        r["source_placement"] = numa_note
-        end_to_end["buffers_sharded"] = r
-        if world == 1:
-            end_to_end["buffers"] = {k: v for k, v in r.items() if k != "per_rank"}  # the name round 2 reported this leg under
-
-        def leg(name, fn):
+        def leg(store, name, fn):
             # an auxiliary leg that cannot run here (no room in /dev/shm, ...) is recorded, it never costs the headline
             # line; a PARITY FAILURE is a SystemExit and still ends the run
+            t0 = time.perf_counter()
             try:
-                return fn()
+                r = fn()
+                if isinstance(r, dict):
+                    r["leg_seconds"] = round(time.perf_counter() - t0, 1)
+                store[name] = r
             except Exception as e:  # noqa: BLE001
-                end_to_end[name] = {"error": repr(e)[:300]}
-                return None
-        if rank == 0 and world == 1 and mode == "full":
-            r = leg("tree", lambda: e2e_tree(ectx, host, job["my_off"], job["my_lens"], args.e2e_files, args.cpu_seconds))
-            if r is not None:
-                end_to_end["tree"], cpu = r
-            del host
-            r = leg("package", e2e_package)
-            if r is not None:
-                end_to_end["package"] = r
-            r = leg("build", lambda: e2e_build(ectx))
-            if r is not None:
-                end_to_end["build"] = r
+                store[name] = {"error": repr(e)[:300]}
+        if args.legs != "off":
+            bctx = Context(device=device, kernel=kern, flags=_lib.FLAG_GPU_ONLY)
+            r = e2e_buffers_sharded(bctx, host, my_off, my_lens, my_want, total_bytes, world, fence, allmax, gather_obj)
+            bctx.close()
+            r["source_placement"] = numa_note
+            end_to_end["buffers_sharded"] = r
+        if full_legs:
+            verify_ms = None
+            t0 = time.perf_counter()
+            if ectx.verify(build, last["yaml"], tar) is not None:
+                raise SystemExit("Verify reports a mismatch on the tree just hashed")
+            verify_ms = (time.perf_counter() - t0) * 1e3
+            end_to_end["tree"] = {"what": "the timed pass itself (value): on-disk tree (tmpfs) -> snaphash_tree -> hashes.yaml",
+                                  "files": n_files + 1, "bytes": total_bytes, "ms": round(ms_step, 2), "GiBps": round(value, 2),
+                                  "h2d_ms": round(e_st["h2d_ms"], 2), "kernel_ms": round(e_st["kernel_ms"], 2),
+                                  "verify_ms": round(verify_ms, 2), "yaml_bytes": len(last["yaml"])}
+            # the shard entry points with one rank must cost what snaphash_tree costs (the N > 1 value is built from them)
+            def tree_world1():
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    with ShardedTree(build, tar, 0, 1) as st1:
+                        y1 = st1.emit(st1.gather(st1.hash(ectx)))
+                    ts.append(time.perf_counter() - t0)
+                if y1 != last["yaml"]:
+                    raise SystemExit("PARITY FAILURE: snaphash_shard_* with one rank differs from snaphash_tree")
+                return {"what": "snaphash_shard_plan/_hash/_emit with world = 1 over the same tree (what N > 1 times, less the all-gather)",
+                        "ms": round(min(ts) * 1e3, 2), "GiBps": round(total_bytes / GiB / min(ts), 2), "best_of": 3}
+            leg(end_to_end, "tree_sharded_world1", tree_world1)
+            leg(end_to_end, "tree_default", lambda: e2e_tree_default(build, tar, total_bytes, last["yaml"], device))
+        del host
+        shutil.rmtree(tmp, ignore_errors=True) if rank == 0 and not use_dist else None
+        if full_legs:
+            leg(end_to_end, "package", e2e_package)
+            sha_rate = cpu["value"] if cpu else 0.47
+            leg(end_to_end, "build", lambda: e2e_build(ectx, sha_rate))
+            leg(end_to_end, "breakeven", e2e_breakeven)
         ectx.close()
-    if rank == 0 and world == 1 and not force_dist and args.cpu_seconds > 0:
-        if cpu is None:
-            cpu = cpu_baseline_buffers(tree, args.cpu_seconds)
-        cpu["all_cores"] = cpu_pool_leg(tree, 3.0)
+        rctx.close()
+        if full_legs:
+            configs = {}
+            for name in ("C1", "C5", "C3"):
+                leg(configs, name, lambda nm=name: config_leg(nm, device, kern, 3.0 if args.cpu_seconds > 0 else 0.0))
 
-    if rank == 0:
-        st = job["stats"]
-        ms_step = job["elapsed"] / args.steps * 1e3
-        value = job["total_bytes"] / 2**30 / (job["elapsed"] / args.steps)
-        k_ms = job["kernel_ms"]
-        achieved = job["my_bytes"] / (k_ms * 1e-3) / 1e9
-        kname = _lib.KERNEL_NAMES.get(st["kernel_used"], "sha512_wide_kernel")
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % kname.replace("<", "_").replace(">", ""))
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            # PMC traffic is a per-launch figure of ONE workload: only quote it for that workload
-            if tj.get("workload", "C2") == args.workload and world == 1 and tj.get("bytes_per_launch", job["my_bytes"]) == job["my_bytes"]:
-                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
-        wl = "%s: %s%d files%s, HBM-resident, LPT-sharded over %d GPU(s)%s" % (
-            args.workload, "ONE tree of " if ntrees == 1 else "%d trees, " % ntrees, len(sizes),
-            " (10 000 x 1 MiB + the 1 MiB archive stand-in)" if args.workload == "C2" and ntrees == 1 else "",
-            world, ", RCCL all-gather of the digest vector" if world > 1 else "")
-        line = {
-            "metric": "GiB/s hashed (whole node), bit-exact hashes.yaml, 10k x 1 MiB tree" if args.workload == "C2" and ntrees == 1
-                      else "GiB/s hashed (whole node), bit-exact hashes.yaml, workload %s x%d" % (args.workload, ntrees),
-            "value": round(value, 3), "unit": "GiB/s",
-            "value_kind": "hbm_resident: file bytes already in HBM when the timed region starts; kernels + digest gather "
-                          "only.  This job is stream-count-bound and flat in N by construction (DESIGN.md sec. 5); the rate "
-                          "that scales with N is end_to_end.buffers_sharded (host memory -> N PCIe links -> digests)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": wl, "files": int(len(sizes)), "bytes": job["total_bytes"], "kernel": kname,
-                       "launches_per_step": int(st["launches"]),
-                       "sha512_blocks_per_step": int(st["blocks"]) if world == 1 else None},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kname, "kernel_ms": round(k_ms, 4), "bytes_per_launch": job["my_bytes"],
-                         "frac_of_valu_ceiling": round(achieved / VALU_SATURATED_GBPS, 4),
-                         "note": "algorithmic bytes = file bytes hashed by rank 0's launch; SHA-512 is integer-VALU "
-                                 "and stream-count bound, not HBM bound (DESIGN.md sec. 4)"},
-            "parity": parity,
-            "ceilings": {"hbm_GBps": HBM_PEAK_GBPS, "valu_saturated_GBps_measured": VALU_SATURATED_GBPS,
-                         "per_stream_MBps_here": round(achieved * 1e3 / max(job["my_streams"], 1), 2),
-                         "source": "profiles/ (regime sweep, saturated-launch PMC)"},
-        }
-        if side_leg is not None:
-            line["other_scaling_leg"] = side_leg
-        if end_to_end is not None:
-            line["end_to_end"] = end_to_end
-        if cpu is not None:
-            line["cpu_baseline"] = cpu
-    ctx.close()
+        if rank == 0:
+            wl = "%s: ONE on-disk tree (tmpfs) of %d files%s -> hashes.yaml, sharded over %d GPU(s)%s" % (
+                args.workload, n_files + 1, " (10 000 x 1 MiB + the 1 MiB archive stand-in)" if args.workload == "C2" else "",
+                world, ", RCCL all-gather of the digest slabs" if world > 1 else "")
+            line = {
+                "metric": "GiB/s hashed (whole node), bit-exact hashes.yaml, 10k x 1 MiB tree" if args.workload == "C2"
+                          else "GiB/s hashed (whole node), bit-exact hashes.yaml, workload %s" % args.workload,
+                "value": round(value, 3), "unit": "GiB/s",
+                "value_kind": "end_to_end (SURVEY sec. 8d-ii): walk + pread + pinned staging + H2D over PCIe + HIP kernels + "
+                              "hashes.yaml, every byte hashed by the kernels; " +
+                              ("snaphash_tree on one GPU" if world == 1 and not force_dist else
+                               "every rank its LPT share of the ONE tree (snaphash_shard_*), one RCCL all-gather, rank 0 writes the YAML") +
+                              ".  The HBM-resident rate is `hbm_resident` / `roofline`, never `value`",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": wl, "files": n_files + 1, "bytes": total_bytes, "kernel": _lib.KERNEL_NAMES.get(r_st["kernel_used"], "?"),
+                           "per_rank": per_rank_step, "tree_placement": numa_note},
+                "roofline": roofline_of(k_ms, int(my_lens.sum()), r_st, args.workload, world),
+                "hbm_resident": {"what": "the same streams already in HBM (snaphash_sha512_device), every rank its share; wall per pass, MAX over ranks",
+                                 "ms_per_pass": round(r_wall * 1e3, 4), "GiBps": round(total_bytes / GiB / r_wall, 3),
+                                 "launches_timed": args.resident_steps,
+                                 "note": "stream-count-bound: 10 001 streams advance no faster on 8 GPUs than on one, so this rate is "
+                                         "flat in N by construction (DESIGN.md sec. 5)"},
+                "parity": parity,
+                "ceilings": {"hbm_GBps": HBM_PEAK_GBPS, "valu_saturated_GBps_measured": VALU_SATURATED_GBPS,
+                             "per_stream_MBps_here": round(int(my_lens.sum()) / (k_ms * 1e-3) / 1e6 / max(len(my_paths), 1), 2),
+                             "pcie_link_GBps_measured": 55.3, "source": "profiles/ (regime sweep, saturated-launch PMC, r04_shard_probe)"},
+            }
+            if end_to_end:
+                line["end_to_end"] = end_to_end
+            if configs:
+                line["configs"] = configs
+            if cpu is not None:
+                line["cpu_baseline"] = cpu
+    finally:
+        if use_dist:
+            try:
+                dist.barrier()
+            except Exception:  # noqa: BLE001
+                pass
+        if rank == 0 and tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
     if use_dist:
-        dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
+    if rank == 0 and line is not None:
         # ---- N > 1: the same tree through ONE process and the C ABI's device list (what the Go caller reaches over
         # cgo): in-library LPT shards, one NUMA-placed staging engine per GPU, single-process RCCL gather.  Run when
         # the ranks have let go of their GPUs, in a child process with a time limit: the line never depends on it. ----
-        if world > 1 and os.environ.get("SNAPHASH_BENCH_NO_INLIB") != "1" and args.workload in ("C1", "C2", "C5"):
+        if world > 1 and not same_gpu and os.environ.get("SNAPHASH_BENCH_NO_INLIB") != "1":
             import subprocess
             torch.cuda.empty_cache()
             try:
@@ -610,9 +902,8 @@ def main():
                 inlib = json.loads(lines[-1]) if lines else {"error": "rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
             except Exception as e:  # a time-out or a missing RCCL must not cost the headline
                 inlib = {"error": repr(e)[:400]}
-            if "sha512_of_digest_vector" in inlib:
-                inlib["same_digest_vector_as_the_timed_path"] = inlib["sha512_of_digest_vector"] == parity["sha512_of_digest_vector"]
             line["in_library_multi_gpu"] = inlib
+        line["bench_seconds"] = round(time.perf_counter() - t_start, 1)
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()
 

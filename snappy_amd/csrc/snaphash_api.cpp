@@ -48,7 +48,8 @@ namespace {
 
 constexpr uint64_t kDefaultStaging = 256ull << 20;
 constexpr uint64_t kAlign = 256;          // placement of a segment inside a staging buffer
-constexpr uint64_t kMinSegment = 64u << 10; // least a stream is given of a slot, unless it ends there
+constexpr uint64_t kMinSegment = 64u << 10;    // least a FILE stream is given of a slot, unless it ends there (an open + close per segment)
+constexpr uint64_t kMinSegmentMem = 16u << 10; // the same for a stream in caller memory (a copy has no such cost)
 constexpr uint32_t kTargetStreams = 4096; // streams per batch the engine aims for (keeps the kernel ahead of PCIe)
 
 struct EventPair { hipEvent_t a = nullptr, b = nullptr; int kind = 0; }; // kind 0 SHA-512 kernels, 1 h2d, 2 deflate kernels
@@ -486,6 +487,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     std::atomic<int> first_err{0};
     std::atomic<int64_t> first_err_src{-1};
     std::vector<ReadOp> ops;
+    const bool from_memory = src[0].mem != nullptr;
     const uint64_t S_full = slot_bytes;
     unsigned batch = 0;
     double t_wait = 0, t_plan = 0, t_read = 0, t_launch = 0; // where the host side of the engine spends its time (SNAPHASH_TRACE_TREE)
@@ -498,15 +500,25 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         t_wait += tb1 - tb0;
         // What a stream gets of this slot: its share by remaining length (so that long and short streams end in the
         // same batch -- a long stream served a fixed slice per batch would still be running, alone, long after the
-        // others: the per-stream rate of the kernels is what it is), but at least kMinSegment (a file is opened once per
+        // others: the per-stream rate of the kernels is what it is), but at least a floor (a file is opened once per
         // batch it appears in).  Equal streams (config 2) fill a slot kTargetStreams at a time, as before.
-        // The first batches are short (1/8, 1/4, 1/2 of a slot): nothing overlaps the first fill and the first copy, so the
-        // pipeline starts on a small one.  Invisible on a 10 GiB job; a tenth of the time of the 1.3 GiB shard one of
-        // eight ranks gets.
-        const uint64_t S = batch < 3 ? std::max<uint64_t>((S_full >> (3 - batch)) & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20)) : S_full;
+        // Both ends of a job of several slots are tapered: nothing overlaps the first fill and the
+        // first copy, and nothing overlaps the last copy and the last kernel, so the first batches are 1/8, 1/4, 1/2 of
+        // a slot and the last ones halve what is left -- invisible on a 10 GiB job, a fifth of the time of the 1.3 GiB
+        // shard one of eight ranks gets.  A job that fits one slot is one batch.
         long double total_rem = 0;
         for (uint32_t id : active) total_rem += (long double)(src[id].gpu_len - done[id]);
-        const uint64_t floor_q = std::max<uint64_t>(kMinSegment, (S / kTargetStreams) & ~(uint64_t)(kAlign - 1));
+        const uint64_t seg_floor = from_memory ? kMinSegmentMem : kMinSegment;
+        uint64_t S = S_full;
+        if (job_bytes + kAlign * n > S_full) {
+            if (batch < 3) S = std::max<uint64_t>((S_full >> (3 - batch)) & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20));
+            if (total_rem < 2 * (long double)S) { // the end: half of what is left, while every stream can still get its floor
+                const uint64_t half = ((uint64_t)(total_rem / 2) + kAlign * active.size()) & ~(uint64_t)(kAlign - 1);
+                const uint64_t least = std::max<uint64_t>(S_full >> 5, (seg_floor + kAlign) * active.size());
+                if (half >= least) S = std::min(S, half);
+            }
+        }
+        const uint64_t floor_q = std::max<uint64_t>(seg_floor, (S / kTargetStreams) & ~(uint64_t)(kAlign - 1));
         rc = ensure_jobs(c, &sl.h_jobs, &sl.d_jobs, &sl.jobs_cap, active.size());
         if (rc) return rc;
 

@@ -78,9 +78,7 @@ class ShardedTree:
     def hash(self, ctx, out=None):
         """Hashes this rank's members on ctx; returns the slab as a numpy [rows, 64] uint8 array (out: reuse one)."""
         slab = out if out is not None else np.zeros((self.rows, 64), dtype=np.uint8)
-        rc = _lib.lib().snaphash_shard_hash(ctx._h, self._h, slab.ctypes.data)
-        if rc:
-            raise _lib.SnaphashError(rc, ctx.last_error())
+        ctx._check(_lib.lib().snaphash_shard_hash(ctx._h, self._h, slab.ctypes.data))
         return slab
 
     def gather(self, slab, device=None, group=None):

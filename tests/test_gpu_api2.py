@@ -32,7 +32,7 @@ def test_two_engines_behind_one_ctx_golden_and_oracle(built_lib, oracle, tmp_pat
     from snappy_amd import Context, _lib
     build, tar = trees.make_simple_tree(str(tmp_path / "g"))
     want = open(os.path.join(GOLDEN, "hashes_simple.yaml"), "rb").read()
-    with Context(devices=[0, 0], flags=_lib.FLAG_CHECK_GATHER) as c:
+    with Context(devices=[0, 0], flags=_lib.FLAG_CHECK_GATHER | _lib.FLAG_GPU_ONLY) as c:
         assert c.tree(build, tar) == want
         ex = c.stats_ex()
         assert ex["n_devices"] == 2 and ex["gather_kind"] == 2
@@ -56,7 +56,7 @@ def test_all_visible_devices_and_rccl_gather(built_lib, oracle):
     import torch
     from snappy_amd import Context, _lib
     bufs = [os.urandom(int(n)) for n in _ragged_sizes(300, 22, 1 << 16)]
-    with Context(devices=[-1], flags=_lib.FLAG_CHECK_GATHER) as c:
+    with Context(devices=[-1], flags=_lib.FLAG_CHECK_GATHER | _lib.FLAG_GPU_ONLY) as c:
         got = c.sha512_buffers(bufs)
         ex = c.stats_ex()
     assert ex["n_devices"] == torch.cuda.device_count()
@@ -71,7 +71,7 @@ def test_rccl_gather_path_with_one_rank(built_lib, oracle):
     the device's own copy -- the same code an 8-GPU ctx runs, on the one GPU this box has."""
     from snappy_amd import Context, _lib
     bufs = [os.urandom(int(n)) for n in _ragged_sizes(200, 26, 1 << 15)]
-    with Context(flags=_lib.FLAG_FORCE_GATHER | _lib.FLAG_CHECK_GATHER) as c:
+    with Context(flags=_lib.FLAG_FORCE_GATHER | _lib.FLAG_CHECK_GATHER | _lib.FLAG_GPU_ONLY) as c:
         got = c.sha512_buffers(bufs)
         ex = c.stats_ex()
         assert ex["gather_kind"] == 1 and ex["gather_checked"] == 1, ex

@@ -35,7 +35,7 @@ n = len(sizes)
 ptrs = (ctypes.c_void_p * n)(*[host.ctypes.data + int(o) for o in off])
 lens = (ctypes.c_uint64 * n)(*[int(x) for x in sizes])
 out = ctypes.create_string_buffer(64 * n)
-with Context(devices=devices, flags=_lib.FLAG_CHECK_GATHER) as c:
+with Context(devices=devices, flags=_lib.FLAG_CHECK_GATHER | _lib.FLAG_GPU_ONLY) as c:
     best = None
     for rep in range(3):
         t0 = time.perf_counter()

@@ -367,8 +367,14 @@ typedef struct snaphash_engine_info {
     uint32_t fill_threads; /* most staging-fill threads the engine uses at a time */
     uint32_t n_cpus;       /* CPUs of numa_node the fill threads are bound to (0 = not bound) */
     char pci_bus_id[32];
+    /* ---- ABI 4 (filled when struct_size covers them; an ABI 3 caller's shorter struct is still accepted) ---- */
+    uint64_t pinned_bytes; /* pinned host memory the engine holds right now (staging slots, job arrays, deflate buffers) */
+    uint64_t hbm_bytes;    /* device memory it holds (staging slots, chaining values, digests, scratch, gather buffer) */
 } snaphash_engine_info;
 int snaphash_get_engine_info(const snaphash_ctx *ctx, uint32_t i, snaphash_engine_info *out);
+/* The CPUs engine i's fill threads are bound to (ABI 4): engines on one NUMA node get disjoint slices of its CPUs (whole
+ * cores: a slice of every SMT sibling run).  *n_cpus = how many; cpus (may be NULL) receives up to cap of them. */
+int snaphash_get_engine_cpus(const snaphash_ctx *ctx, uint32_t i, int32_t *cpus, size_t cap, size_t *n_cpus);
 
 /* ---- ABI 4: the plan of a call, host-only (no device needed) ------------------------------------------------
  * What the planner (snaphash_config.host_threads) decides for n streams of the given lengths under a cost model;
@@ -422,6 +428,10 @@ void snaphash_shard_free(snaphash_shard *sh);
  * of the PCI function (-1 unknown); cpus (may be NULL) receives up to cap CPU numbers of that node, *n_cpus how many
  * the node has. */
 int snaphash_numa_probe(const char *sysfs_root, const char *pci_bus_id, int32_t *node, int32_t *cpus, size_t cap,
+                        size_t *n_cpus);
+/* Host-only (ABI 4): the CPUs engine `pos` of the `m` engines on NUMA node `node` gets (snaphash_get_engine_cpus on a
+ * live ctx): slice pos of every contiguous run of the node's cpulist. */
+int snaphash_numa_slice(const char *sysfs_root, int32_t node, uint32_t pos, uint32_t m, int32_t *cpus, size_t cap,
                         size_t *n_cpus);
 
 #ifdef __cplusplus

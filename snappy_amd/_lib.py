@@ -30,7 +30,7 @@ EXPORTS = [
     "snaphash_batch_begin", "snaphash_batch_append", "snaphash_batch_end", "snaphash_batch_finish", "snaphash_batch_abort",
     "snaphash_tar_create", "snaphash_tar_create_fn", "snaphash_gzip_buffer", "snaphash_get_targz_stats",
     "snaphash_get_engine_info", "snaphash_numa_probe",
-    "snaphash_plan_streams", "snaphash_usable_cpus", "snaphash_cgroup_cpu_quota",
+    "snaphash_get_engine_cpus", "snaphash_numa_slice", "snaphash_plan_streams", "snaphash_usable_cpus", "snaphash_cgroup_cpu_quota",
     "snaphash_shard_plan", "snaphash_shard_rows", "snaphash_shard_count", "snaphash_shard_streams", "snaphash_shard_bytes",
     "snaphash_shard_path", "snaphash_shard_hash", "snaphash_shard_emit", "snaphash_shard_free",
 ]
@@ -55,7 +55,7 @@ class StatsEx(ctypes.Structure):
 class EngineInfo(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("numa_node", ctypes.c_int32),
                 ("staging_node", ctypes.c_int32), ("fill_threads", ctypes.c_uint32), ("n_cpus", ctypes.c_uint32),
-                ("pci_bus_id", ctypes.c_char * 32)]
+                ("pci_bus_id", ctypes.c_char * 32), ("pinned_bytes", ctypes.c_uint64), ("hbm_bytes", ctypes.c_uint64)]
 
 
 class PlanModel(ctypes.Structure):
@@ -180,6 +180,8 @@ def lib():
     L.snaphash_shard_emit.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.snaphash_shard_free.argtypes = [vp]
     L.snaphash_shard_free.restype = None
+    L.snaphash_numa_slice.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32, vp, sz, ctypes.POINTER(sz)]
+    L.snaphash_get_engine_cpus.argtypes = [vp, ctypes.c_uint32, vp, sz, ctypes.POINTER(sz)]
     L.snaphash_plan_streams.argtypes = [u64p, sz, ctypes.POINTER(PlanModel), vp]
     L.snaphash_usable_cpus.argtypes = []
     L.snaphash_usable_cpus.restype = ctypes.c_uint32
@@ -424,6 +426,13 @@ class Context:
         out = {f[0]: getattr(e, f[0]) for f in EngineInfo._fields_}
         out["pci_bus_id"] = e.pci_bus_id.decode()
         return out
+
+    def engine_cpus(self, i):
+        n = ctypes.c_size_t()
+        self._check(lib().snaphash_get_engine_cpus(self._h, i, None, 0, ctypes.byref(n)))
+        buf = (ctypes.c_int32 * max(n.value, 1))()
+        self._check(lib().snaphash_get_engine_cpus(self._h, i, buf, n.value, ctypes.byref(n)))
+        return list(buf[:n.value])
 
     def device_stats(self, i):
         s, d = Stats(), ctypes.c_int32()

@@ -77,6 +77,20 @@ std::vector<int> numa_cpus_of_node(const std::string& sysfs_root, int node)
     return parse_cpulist(text);
 }
 
+std::vector<int> slice_cpus(const std::vector<int>& all, size_t pos, size_t m)
+{
+    if (m < 2 || pos >= m) return all;
+    std::vector<int> mine;
+    for (size_t a = 0; a < all.size();) {
+        size_t b = a + 1;
+        while (b < all.size() && all[b] == all[b - 1] + 1) ++b;
+        const size_t len = b - a;
+        for (size_t i = a + len * pos / m; i < a + len * (pos + 1) / m; ++i) mine.push_back(all[i]);
+        a = b;
+    }
+    return mine;
+}
+
 int numa_node_count(const std::string& sysfs_root)
 {
     int n = 0;

@@ -25,6 +25,10 @@ int numa_node_of_pci(const std::string& sysfs_root, const std::string& bdf);
 std::vector<int> numa_cpus_of_node(const std::string& sysfs_root, int node);
 std::vector<int> parse_cpulist(const std::string& text);
 int numa_node_count(const std::string& sysfs_root);
+// Engines that share a NUMA node share its CPUs: engine `pos` of the `m` on a node gets slice `pos` of every contiguous
+// run of the node's cpulist (a run is one SMT sibling set on the hosts seen: "0-63,128-191"), so the fill threads of two
+// engines never sit on one core and a core's two hardware threads stay with one engine.
+std::vector<int> slice_cpus(const std::vector<int>& all, size_t pos, size_t m);
 
 // Memory policy of the calling thread: prefer `node` for the allocations that follow (set_mempolicy MPOL_PREFERRED;
 // no libnuma: the raw system calls), then back to what the thread had before -- the caller's own policy (numactl,

@@ -1172,6 +1172,19 @@ try {
         }
         x->dev.push_back(std::move(c));
     }
+    // engines that share a NUMA node get disjoint slices of its CPUs (hostfill.h slice_cpus)
+    if (numa_on && x->dev.size() > 1) {
+        for (size_t k = 0; k < x->dev.size(); ++k) {
+            DevCtx* c = x->dev[k].get();
+            if (c->numa_node < 0) continue;
+            size_t m = 0, pos = 0;
+            for (size_t j = 0; j < x->dev.size(); ++j)
+                if (x->dev[j]->numa_node == c->numa_node) { if (j == k) pos = m; ++m; }
+            if (m < 2) continue;
+            const std::vector<int> mine = slice_cpus(numa_cpus_of_node(sysfs, c->numa_node), pos, m);
+            if (!mine.empty()) c->pool.configure(256, mine);
+        }
+    }
     *out = x.release();
     return SNAPHASH_OK;
 } catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
@@ -2286,20 +2299,71 @@ try {
     return SNAPHASH_ENOMEM;
 }
 
+// what an engine holds right now: pinned host bytes and HBM bytes (staging slots, job arrays, chaining values, digests,
+// comparison and deflate scratch)
+static void engine_footprint(const snaphash_ctx* x, size_t i, uint64_t* pinned, uint64_t* hbm)
+{
+    const DevCtx* d = x->dev[i].get();
+    uint64_t p = 0, h = 0;
+    for (const Slot& s : d->slot) {
+        if (s.h_buf) p += s.cap;
+        if (s.d_buf) h += s.cap + 256;
+        p += s.jobs_cap * sizeof(Job);
+        h += s.jobs_cap * sizeof(Job);
+    }
+    p += d->jobs_cap * sizeof(Job) + d->chunks_cap * sizeof(CmpChunk);
+    h += d->jobs_cap * sizeof(Job) + d->chunks_cap * sizeof(CmpChunk) + d->state_cap * 64 + d->digests_cap * 64 + d->equal_cap;
+    if (d->z_chunks) { // deflate scratch (targz.inc ensure_deflate)
+        const uint64_t nch = d->z_chunks;
+        h += 2 * nch * (uint64_t)kDeflateSlot + nch * (uint64_t)kDeflateTokWords * 4 + nch * 4 + (nch + 1) * 8;
+        p += nch * 4 + (nch + 1) * 8 + 2 * nch * (uint64_t)kDeflateSlot;
+    }
+    if (i < x->d_gather.size() && x->d_gather[i]) h += (uint64_t)x->dev.size() * x->gather_cap * 64;
+    *pinned = p;
+    *hbm = h;
+}
+
 int snaphash_get_engine_info(const snaphash_ctx* c, uint32_t i, snaphash_engine_info* out)
 try {
-    if (!c || !out || i >= c->dev.size() || out->struct_size < sizeof(snaphash_engine_info)) return SNAPHASH_EINVAL;
+    constexpr uint32_t kAbi3Size = (uint32_t)offsetof(snaphash_engine_info, pinned_bytes);
+    if (!c || !out || i >= c->dev.size() || out->struct_size < kAbi3Size) return SNAPHASH_EINVAL;
+    const uint32_t have = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(snaphash_engine_info));
     const DevCtx* d = c->dev[i].get();
-    memset(out, 0, sizeof *out);
-    out->struct_size = sizeof *out;
-    out->device = d->device;
-    out->numa_node = d->numa_node;
-    out->staging_node = d->staging_node;
-    out->fill_threads = d->fill_cap;
-    out->n_cpus = (uint32_t)d->pool.cpus().size();
-    snprintf(out->pci_bus_id, sizeof out->pci_bus_id, "%s", d->pci_bus_id.c_str());
+    snaphash_engine_info v;
+    memset(&v, 0, sizeof v);
+    v.struct_size = have;
+    v.device = d->device;
+    v.numa_node = d->numa_node;
+    v.staging_node = d->staging_node;
+    v.fill_threads = d->fill_cap;
+    v.n_cpus = (uint32_t)d->pool.cpus().size();
+    snprintf(v.pci_bus_id, sizeof v.pci_bus_id, "%s", d->pci_bus_id.c_str());
+    engine_footprint(c, i, &v.pinned_bytes, &v.hbm_bytes);
+    memcpy(out, &v, have);
     return SNAPHASH_OK;
 } catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
+    return SNAPHASH_ENOMEM;
+}
+
+int snaphash_get_engine_cpus(const snaphash_ctx* c, uint32_t i, int32_t* cpus, size_t cap, size_t* n_cpus)
+try {
+    if (!c || i >= c->dev.size() || !n_cpus) return SNAPHASH_EINVAL;
+    const std::vector<int>& v = c->dev[i]->pool.cpus();
+    *n_cpus = v.size();
+    for (size_t k = 0; cpus && k < v.size() && k < cap; ++k) cpus[k] = v[k];
+    return SNAPHASH_OK;
+} catch (...) {
+    return SNAPHASH_ENOMEM;
+}
+
+int snaphash_numa_slice(const char* sysfs_root, int32_t node, uint32_t pos, uint32_t m, int32_t* cpus, size_t cap, size_t* n_cpus)
+try {
+    if (!sysfs_root || !n_cpus) return SNAPHASH_EINVAL;
+    const std::vector<int> v = slice_cpus(numa_cpus_of_node(sysfs_root, node), pos, m);
+    *n_cpus = v.size();
+    for (size_t k = 0; cpus && k < v.size() && k < cap; ++k) cpus[k] = v[k];
+    return SNAPHASH_OK;
+} catch (...) {
     return SNAPHASH_ENOMEM;
 }
 

@@ -8,55 +8,122 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 
 namespace snaphash {
 
 namespace {
 
-// appends path's children (recursively); `path` itself is ents[self].  Returns the index of the entry at which the
-// serial walk would have failed (errno in *err_no), or -1.
-int64_t walk_names(const std::string& path, std::vector<WalkEntry>& ents, size_t self, int* err_no)
+// One directory, listed: its children byte-wise sorted (sort.Strings), each with the type the filesystem gave for it
+// (or, where it gave none, the Lstat taken on the spot).
+struct Child {
+    std::string name;
+    unsigned char type = DT_UNKNOWN;
+    struct stat st;
+    bool have_st = false;
+    int lstat_errno = 0;
+    int64_t dir = -1; // index of this child's own listing when it is a directory
+};
+struct DirList {
+    std::string path;
+    bool open_failed = false;
+    std::vector<Child> kids;
+};
+
+void list_dir(DirList& dl)
 {
-    DIR* d = opendir(path.c_str());
-    if (!d) {
+    DIR* d = opendir(dl.path.c_str());
+    if (!d) { dl.open_failed = true; return; }
+    while (struct dirent* de = readdir(d)) {
+        if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
+        Child c;
+        c.name = de->d_name;
+        c.type = de->d_type;
+        dl.kids.push_back(std::move(c));
+    }
+    closedir(d);
+    std::sort(dl.kids.begin(), dl.kids.end(), [](const Child& a, const Child& b) { return a.name < b.name; });
+    for (Child& c : dl.kids)
+        if (c.type == DT_UNKNOWN) { // this filesystem does not say: look now
+            if (lstat((dl.path + "/" + c.name).c_str(), &c.st) != 0) c.lstat_errno = errno;
+            else { c.have_st = true; c.type = S_ISDIR(c.st.st_mode) ? DT_DIR : DT_REG; }
+        }
+}
+
+// Pre-order assembly of the listings: appends dirs[di]'s children (recursively); dirs[di] itself is ents[self].  Returns
+// the index of the entry at which the serial walk would have failed (errno in *err_no), or -1.
+int64_t assemble(const std::vector<DirList>& dirs, size_t di, std::vector<WalkEntry>& ents, size_t self, int* err_no)
+{
+    const DirList& dl = dirs[di];
+    if (dl.open_failed) {
         // filepath.Walk: `names, err := readDirNames(path); if err != nil { return walkFn(path, info, err) }` -- the
         // callback runs a SECOND time for the directory, and neither of the reference's callbacks looks at the err
         // it is handed (snappy/build.go:228 ignores it, clickdeb/deb.go:285-286 shadows it with its own Lstat): the
         // entry is emitted again and the walk goes on behind it.
         WalkEntry again;
-        again.path = path;
+        again.path = dl.path;
         again.st = ents[self].st;
         again.have_st = ents[self].have_st;
         ents.push_back(std::move(again));
-        (void)err_no;
         return -1;
     }
-    std::vector<std::pair<std::string, unsigned char>> names;
-    while (struct dirent* de = readdir(d)) {
-        if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
-        names.emplace_back(de->d_name, de->d_type);
-    }
-    closedir(d);
-    std::sort(names.begin(), names.end(), [](const auto& a, const auto& b) { return a.first < b.first; }); // sort.Strings: byte-wise
-    for (const auto& nt : names) {
+    for (const Child& c : dl.kids) {
         WalkEntry e;
-        e.path = path + "/" + nt.first;
-        bool is_dir = nt.second == DT_DIR;
-        if (nt.second == DT_UNKNOWN) { // this filesystem does not say: look now
-            if (lstat(e.path.c_str(), &e.st) != 0) { *err_no = errno; ents.push_back(std::move(e)); return (int64_t)ents.size() - 1; }
-            e.have_st = true;
-            is_dir = S_ISDIR(e.st.st_mode);
-        }
+        e.path = dl.path + "/" + c.name;
+        if (c.lstat_errno) { *err_no = c.lstat_errno; ents.push_back(std::move(e)); return (int64_t)ents.size() - 1; }
+        if (c.have_st) { e.st = c.st; e.have_st = true; }
         const size_t me = ents.size();
         ents.push_back(std::move(e));
-        if (is_dir) {
-            const std::string sub = ents[me].path; // ents may reallocate below
-            const int64_t bad = walk_names(sub, ents, me, err_no);
+        if (c.dir >= 0) {
+            const int64_t bad = assemble(dirs, (size_t)c.dir, ents, me, err_no);
             if (bad >= 0) return bad;
         }
     }
     return -1;
+}
+
+unsigned walk_threads(size_t items, size_t per_thread)
+{
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, usable_cpus()), items / per_thread));
+}
+
+// Lists the tree under root level by level: the directories of one level are independent, so they are listed on a few
+// threads (a 10 000-file tree in 100 directories: ~6 ms of readdir + sort on one thread); then the listings are put
+// together in Walk's pre-order.
+int64_t walk_names(const std::string& root, std::vector<WalkEntry>& ents, int* err_no)
+{
+    std::vector<DirList> dirs(1);
+    dirs[0].path = root;
+    size_t lo = 0;
+    while (lo < dirs.size()) {
+        const size_t hi = dirs.size();
+        const unsigned T = walk_threads(hi - lo, 4);
+        std::atomic<size_t> next{lo};
+        auto work = [&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= hi) return;
+                list_dir(dirs[i]);
+            }
+        };
+        {
+            ThreadJoiner th;
+            for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work);
+            work();
+            th.join_all();
+        }
+        for (size_t i = lo; i < hi; ++i) // the next level (dirs may reallocate: by index)
+            for (size_t k = 0; k < dirs[i].kids.size(); ++k)
+                if (dirs[i].kids[k].type == DT_DIR && !dirs[i].kids[k].lstat_errno) {
+                    dirs[i].kids[k].dir = (int64_t)dirs.size();
+                    DirList sub;
+                    sub.path = dirs[i].path + "/" + dirs[i].kids[k].name;
+                    dirs.push_back(std::move(sub));
+                }
+        lo = hi;
+    }
+    return assemble(dirs, 0, ents, 0, err_no);
 }
 
 } // namespace
@@ -78,10 +145,10 @@ int walk_entries(const char* root_c, std::vector<WalkEntry>& ents, int* err_no, 
     ents[0].have_st = true;
     int dir_errno = 0;
     int64_t dir_bad = -1; // entry whose children could not be listed, or whose look-ahead Lstat failed
-    if (S_ISDIR(ents[0].st.st_mode)) dir_bad = walk_names(root, ents, 0, &dir_errno);
+    if (S_ISDIR(ents[0].st.st_mode)) dir_bad = walk_names(root, ents, &dir_errno);
 
     const size_t n = ents.size();
-    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(12u, std::max(1u, std::thread::hardware_concurrency())), n / 2048));
+    const unsigned T = walk_threads(n, 512);
     std::vector<int64_t> bad(T, -1);
     std::vector<int> bad_errno(T, 0);
     auto work = [&](unsigned t) {

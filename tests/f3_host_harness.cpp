@@ -15,6 +15,7 @@
 #include "deflate_model.h"
 #include "../snappy_amd/csrc/tarpack.cpp"
 #include "../snappy_amd/csrc/walk.cpp"
+#include "../snappy_amd/csrc/hostfill.cpp" // walk.cpp sizes its thread pools with usable_cpus()
 
 using namespace snaphash;
 

@@ -21,7 +21,7 @@ from conftest import ROOT
 def f3(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("f3") / "libf3host.so")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so,
-                           os.path.join(ROOT, "tests", "f3_host_harness.cpp")])
+                           os.path.join(ROOT, "tests", "f3_host_harness.cpp"), "-pthread"])
     L = ctypes.CDLL(so)
     L.f3_model_gzip.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.f3_model_gzip.restype = ctypes.c_void_p
@@ -259,7 +259,7 @@ int main(int argc, char** argv) {
 }
 ''' % (ROOT, ROOT))
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                           "-o", exe, str(src)])
+                           "-o", exe, str(src), "-pthread"])
     root = str(tmp_path / "src")
     os.makedirs(root)
     _make_tree(root)

@@ -403,6 +403,74 @@ def test_default_configuration_through_tree_verify_and_the_producer(built_lib, o
         assert c.tree(build, tar) == want
 
 
+def test_eight_engines_in_one_process(built_lib, oracle):
+    """Row e's in-library form as an 8-GPU node will run it, rehearsed on the one GPU this pool gives a test: devices =
+    {0} x 8 (eight engines, copy gather: RCCL needs distinct devices) over BASELINE config 2's own list -- 10 001 x 1 MiB,
+    1 250 per engine.  Digests = the single-engine vector = the oracle on a sample; every engine worked; engines on one
+    NUMA node hold disjoint CPU slices and their staging sits on the GPU's node; pinned and HBM footprints are what
+    3 slots of 256 MiB per engine come to.  (seam: snappy/build.go:517-520.)"""
+    import ctypes
+    import time
+    import torch
+    from snappy_amd import Context, _lib, synthetic
+    n = 10001
+    avail = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) * 1024
+    if avail < (40 << 30):
+        n = 2001  # a small host: the same shape at a fifth of the size
+    sizes = np.full(n, 1 << 20, dtype=np.uint64)
+    off, total = synthetic.pack_offsets(sizes)
+    with Context(device=0) as c0:
+        dev = torch.empty(total, dtype=torch.uint8, device="cuda")
+        c0.fill_synthetic_device(dev.data_ptr(), off, sizes, np.arange(n, dtype=np.uint64))
+        torch.cuda.synchronize()
+        host = dev.cpu().numpy()
+        del dev
+        torch.cuda.empty_cache()
+    ptrs = (ctypes.c_void_p * n)(*[host.ctypes.data + int(o) for o in off])
+    lens = (ctypes.c_uint64 * n)(*[1 << 20] * n)
+    L = _lib.lib()
+
+    def run(c):
+        out = ctypes.create_string_buffer(64 * n)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            assert L.snaphash_sha512_buffers(c._h, ptrs, lens, n, out) == 0
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return out.raw, best
+    free0, _ = torch.cuda.mem_get_info()
+    with Context(devices=[0] * 8, flags=_lib.FLAG_GPU_ONLY) as c:
+        got8, t8 = run(c)
+        ex = c.stats_ex()
+        assert ex["n_devices"] == 8 and ex["gather_kind"] == 2 and ex["host_bytes"] == 0 and ex["gpu_bytes"] == n << 20
+        streams = [c.device_stats(i)["streams"] for i in range(8)]
+        assert sum(streams) == n and min(streams) >= n // 8 and max(streams) <= n // 8 + 1  # LPT over equal streams
+        infos = [c.engine_info(i) for i in range(8)]
+        cpus = [set(c.engine_cpus(i)) for i in range(8)]
+        free1, _ = torch.cuda.mem_get_info()
+        for i, e in enumerate(infos):
+            assert e["device"] == 0 and e["fill_threads"] >= 2
+            if e["numa_node"] >= 0:
+                assert e["staging_node"] in (-1, e["numa_node"])  # pinned staging on the GPU's node
+                assert cpus[i], "an engine on a known node has a CPU slice"
+            want_slots = 3 if (streams[i] << 20) > 2 * (256 << 20) else 2
+            assert want_slots * (256 << 20) <= e["pinned_bytes"] <= want_slots * (256 << 20) + (8 << 20), e
+            assert want_slots * (256 << 20) <= e["hbm_bytes"] <= want_slots * (256 << 20) + (16 << 20), e
+        for i in range(8):
+            for j in range(i):
+                assert not (cpus[i] & cpus[j]), "engines %d and %d share CPUs" % (i, j)
+        hbm = sum(e["hbm_bytes"] for e in infos)
+        assert abs((free0 - free1) - hbm) < (1 << 30), (free0 - free1, hbm)  # what the library says it holds is what the device lost
+    with Context(device=0, flags=_lib.FLAG_GPU_ONLY) as c:
+        got1, t1 = run(c)
+    assert got8 == got1
+    for i in [0, 1, n // 2, n - 1] + [int(x) for x in np.random.default_rng(2).integers(0, n, size=12)]:
+        assert got8[64 * i:64 * i + 64] == oracle.sha512(host[int(off[i]):int(off[i]) + (1 << 20)].tobytes())
+    print("eight engines on one GPU: %d x 1 MiB in %.1f ms (one engine: %.1f ms); pinned %.2f GiB, HBM %.2f GiB; CPU slices %s" %
+          (n, t8 * 1e3, t1 * 1e3, sum(e["pinned_bytes"] for e in infos) / 2**30, hbm / 2**30, [len(s) for s in cpus]))
+
+
 def test_engine_info_and_numa_flags(built_lib):
     from snappy_amd import Context, _lib
     with Context(devices=[0, 0]) as c:

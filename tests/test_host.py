@@ -32,6 +32,7 @@ def test_struct_layouts_match_header(built_lib):
     assert ctypes.sizeof(_lib.Stats) == 56
     assert ctypes.sizeof(_lib.Mismatch) == 8 + 4096
     assert ctypes.sizeof(_lib.Record) == 32
+    assert ctypes.sizeof(_lib.EngineInfo) == 72 and _lib.EngineInfo.pinned_bytes.offset == 56  # ABI 3 callers pass 56
     assert ctypes.sizeof(_lib.PlanModel) == 96 and _lib.PlanModel.gpu_seconds.offset == 56  # ABI 4
 
 
@@ -256,7 +257,8 @@ def test_hostpass_under_asan_and_ubsan(tmp_path):
                            "-o", exe, os.path.join(ROOT, "tests", "asan_hostpass.cpp"),
                            os.path.join(ROOT, "snappy_amd", "csrc", "hostpass.cpp"),
                            os.path.join(ROOT, "snappy_amd", "csrc", "yamlscalar.cpp"),
-                           os.path.join(ROOT, "snappy_amd", "csrc", "walk.cpp"), "-pthread"])
+                           os.path.join(ROOT, "snappy_amd", "csrc", "walk.cpp"),
+                           os.path.join(ROOT, "snappy_amd", "csrc", "hostfill.cpp"), "-pthread"])
     build, tar = trees.make_synthetic_tree(str(tmp_path / "t"), [5, 0, 300, 70000, 12, 1, 2, 3])
     r = subprocess.run([exe, build, os.path.join(GOLDEN, "hashes_simple.yaml")], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300)
@@ -359,6 +361,20 @@ def test_numa_probe_on_a_fake_sysfs(built_lib, tmp_path):
         assert node == k // 4
         lo = 64 * node
         assert cpus == list(range(lo, lo + 64)) + list(range(128 + lo, 128 + lo + 64))
+    # four engines on a node: disjoint slices, whole cores (a CPU and its SMT sibling, 128 apart here, stay together)
+    L = _lib.lib()
+    seen = set()
+    for node in (0, 1):
+        for pos in range(4):
+            n = ctypes.c_size_t()
+            buf = (ctypes.c_int32 * 256)()
+            assert L.snaphash_numa_slice(str(sysfs).encode(), node, pos, 4, buf, 256, ctypes.byref(n)) == 0
+            mine = list(buf[:n.value])
+            lo = 64 * node + 16 * pos
+            assert mine == list(range(lo, lo + 16)) + list(range(128 + lo, 128 + lo + 16))
+            assert not (seen & set(mine))
+            seen |= set(mine)
+    assert seen == set(range(256))
     assert _lib.numa_probe(str(sysfs), "0000:aa:00.0") == (-1, [])   # sysfs says "no node"
     assert _lib.numa_probe(str(sysfs), "0000:bb:00.0") == (-1, [])   # unknown function
     assert _lib.numa_probe("/nonexistent", gpus[0]) == (-1, [])

@@ -687,14 +687,15 @@ __device__ __forceinline__ void token_bits(const ChunkLds& L, bool dynamic, bool
 // sizes[c]: bytes chunk c produced; toks: nchunks * kDeflateTokWords words of scratch (the chunk's match tokens).
 __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __restrict__ in, uint64_t n_in, uint8_t* __restrict__ slots,
                                                               uint32_t* __restrict__ sizes, uint32_t* __restrict__ toks, uint32_t chunk0,
-                                                              uint32_t nchunks)
+                                                              uint32_t nchunks, uint32_t nx)
 {
     __shared__ ChunkLds L;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    // Workgroups go round the 8 XCDs (workgroup i to XCD i % 8), each with an L2 of its own; a chunk's window is the 28 KiB
-    // the chunk in front of it also stages.  So an XCD takes a RUN of consecutive chunks, not every eighth: the window is
-    // then in its L2 already (or on its way there) when the neighbour asks for it.
-    const uint32_t nx = 8u, per = gridDim.x / nx, extra = gridDim.x % nx;
+    // Workgroups go round the device's nx XCDs (workgroup i to XCD i % nx; nx = 8 in SPX mode, asked of the device by the
+    // host), each with an L2 of its own; a chunk's window is the 28 KiB the chunk in front of it also stages.  So an XCD
+    // takes a RUN of consecutive chunks, not every nx-th: the window is then in its L2 already (or on its way there) when
+    // the neighbour asks for it.  The mapping is a bijection for any nx, so a wrong nx costs locality, never output.
+    const uint32_t per = gridDim.x / nx, extra = gridDim.x % nx;
     const uint32_t xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
     const uint32_t c = chunk0 + xcd * per + (xcd < extra ? xcd : extra) + slot;
     if (c >= nchunks) return;
@@ -1002,10 +1003,11 @@ __global__ __launch_bounds__(256) void deflate_compact_kernel(const uint8_t* __r
 }
 
 hipError_t launch_deflate_chunks(const uint8_t* d_in, uint64_t n_in, uint8_t* d_slots, uint32_t* d_sizes, uint32_t* d_toks,
-                                 uint32_t chunk0, uint32_t count, uint32_t nchunks, hipStream_t s)
+                                 uint32_t chunk0, uint32_t count, uint32_t nchunks, uint32_t n_xcd, hipStream_t s)
 {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(deflate_chunks_kernel, dim3(count), dim3(1024), 0, s, d_in, n_in, d_slots, d_sizes, d_toks, chunk0, nchunks);
+    if (n_xcd == 0 || n_xcd > 64) n_xcd = 8;
+    hipLaunchKernelGGL(deflate_chunks_kernel, dim3(count), dim3(1024), 0, s, d_in, n_in, d_slots, d_sizes, d_toks, chunk0, nchunks, n_xcd);
     return hipGetLastError();
 }
 

@@ -84,6 +84,7 @@ struct DevCtx {
     hipStream_t copy_stream = nullptr; // H2D of batch k+1 overlaps the kernel of batch k
     uint64_t staging = kDefaultStaging;
     uint32_t kernel_pref = SNAPHASH_KERNEL_AUTO;
+    uint32_t n_xcd = 8; // XCDs (L2 domains) the device presents: 8 in SPX mode; the DEFLATE launch keeps a run of chunks on one
 
     Slot slot[3]; // [0], [1]: every staging user; [2]: a third buffer for the hashing engine alone, allocated when a call
                   // has more than two buffers' worth of bytes (fill k+2 then overlaps kernel k: with two, a job whose
@@ -210,11 +211,18 @@ EventPair* next_events(DevCtx* c, int kind)
 
 void collect_events(DevCtx* c)
 {
+    static const bool trace = getenv("SNAPHASH_TRACE_EVENTS") != nullptr; // the GPU side of a call, batch by batch
     for (size_t i = 0; i < c->ev_used; ++i) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) {
             if (c->ev_pool[i].kind == 0) c->stats.kernel_ms += ms;
             else if (c->ev_pool[i].kind == 1) c->stats.h2d_ms += ms;
+        }
+        if (trace && c->ev_used > 1) {
+            float t0 = 0, t1 = 0;
+            (void)hipEventElapsedTime(&t0, c->ev_pool[0].a, c->ev_pool[i].a);
+            (void)hipEventElapsedTime(&t1, c->ev_pool[0].a, c->ev_pool[i].b);
+            fprintf(stderr, "snaphash engine %d: %s %7.2f .. %7.2f ms\n", c->index, c->ev_pool[i].kind == 0 ? "kernel" : c->ev_pool[i].kind == 1 ? "h2d   " : "other ", t0, t1);
         }
     }
     c->ev_used = 0;
@@ -1152,6 +1160,11 @@ try {
         if (!rc) {
             if (c->staging < (1u << 16)) c->staging = 1u << 16;
             c->fill_cap = fill_cap;
+            { // SPX: 8; a CPX/DPX partition presents fewer
+                int xcc = 0;
+                if (hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && xcc >= 1 && xcc <= 64) c->n_xcd = (uint32_t)xcc;
+                else (void)hipGetLastError();
+            }
             std::vector<int> cpus;
             char bdf[64] = {0};
             if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, dev) == hipSuccess) c->pci_bus_id = bdf;

@@ -317,6 +317,107 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     return best >= kDfMinMatch ? res_pack(best, bdist, byte) : res_pack(0u, 0u, byte);
 }
 
+// ---- searcher, round 4: the lanes of a wave STREAM through positions -----------------------------------------------
+// search_position above gives a wave one tile and the tile costs what its slowest lane costs: on content with long
+// matches a few lanes walk 8 batches while most are done after one or two, and 60 % of the issue slots go to waiting
+// (sources: 17.0 ms per 64 MiB against 10.2 for text).  Here a lane that is done with its position takes
+// the next one of the wave's pool (a tile from the step's queue, as before) at the top of the next batch: the wave stays
+// full until the queue is empty, and a step costs the lanes' average instead of a maximum per tile.  The walk of a
+// position -- batches of four links, check words, extensions, the serial walk's exact result -- is unchanged, so the
+// bytes still equal those of the serial model (tests/deflate_model.h).
+__device__ __forceinline__ void search_segment_stream(ChunkLds& L, const uint8_t* __restrict__ in, uint64_t n_in, uint64_t seg64, uint64_t c1,
+                                                      uint32_t* __restrict__ res, uint32_t lane)
+{
+    uint32_t pool = 0, pool_end = 0; // the wave's pool: positions [pool, pool_end) of the segment (uniform)
+    bool tiles_left = true;
+    bool active = false;             // this lane is in the middle of a position's walk
+    uint32_t rel = 0, p = 0, byte = 0, maxl = 0, best = 0, bdist = 0, left = 0, cur = 0;
+    bool more = false;
+    const uint8_t* gb = in;
+    for (;;) {
+        uint64_t idle = __ballot(!active);
+        while (idle) { // every idle lane takes the next position of the pool; an empty pool takes the next tile of the queue
+            if (pool == pool_end) {
+                if (!tiles_left) break;
+                uint32_t item = 0;
+                if (lane == 0u) item = atomicAdd(&L.queue[1], 1u);
+                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+                if (item >= kSegTiles) { tiles_left = false; break; }
+                while (__hip_atomic_load(&L.across_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= item) __builtin_amdgcn_s_sleep(1);
+                pool = item * 64u;
+                pool_end = pool + 64u;
+            }
+            const uint32_t navail = pool_end - pool;
+            const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+            if (!active && rank < navail) {
+                rel = pool + rank;
+                const uint64_t p64 = seg64 + rel;
+                p = (uint32_t)p64;
+                gb = in + (p64 - p);
+                if (p64 >= c1) {
+                    res[rel] = 0u;
+                } else {
+                    byte = L.data[p & kDataMask];
+                    maxl = (c1 - p64 < 258u) ? (uint32_t)(c1 - p64) : 258u;
+                    if (maxl < kDfMinMatch || p64 + 3u > n_in) {
+                        res[rel] = res_pack(0u, 0u, byte);
+                    } else {
+                        best = kDfMinMatch - 1u; bdist = 0u; left = kDfDepth; cur = p; more = true;
+                        active = true;
+                    }
+                }
+            }
+            const uint32_t nidle = (uint32_t)__builtin_popcountll(idle);
+            pool += nidle < navail ? nidle : navail;
+            idle = __ballot(!active); // (a position that needs no walk leaves its lane idle: it takes another)
+        }
+        if (__ballot(active) == 0ull) break;
+        if (active) { // one batch of the walk: search_position's loop body
+            uint32_t c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0, ncand = 0;
+#define SNAPHASH_DF_LINK(dst)                                                       \
+            if (more && ncand < left) {                                             \
+                const uint32_t d_ = L.ix.ring[cur & kRingMask];                     \
+                if (d_ == 0u || p - (cur - d_) > kDfMaxDist) more = false;          \
+                else { cur -= d_; dst = cur; ++ncand; }                             \
+            }
+            SNAPHASH_DF_LINK(c0_) SNAPHASH_DF_LINK(c1_) SNAPHASH_DF_LINK(c2_) SNAPHASH_DF_LINK(c3_)
+#undef SNAPHASH_DF_LINK
+            const uint32_t off = best >= 3u ? best - 3u : 0u;
+            const uint32_t mine = d32(L, p + off);
+            const uint32_t k0 = *reinterpret_cast<const u32_unaligned*>(gb + c0_ + off), k1 = *reinterpret_cast<const u32_unaligned*>(gb + c1_ + off),
+                           k2 = *reinterpret_cast<const u32_unaligned*>(gb + c2_ + off), k3 = *reinterpret_cast<const u32_unaligned*>(gb + c3_ + off);
+#define SNAPHASH_DF_EVAL(k, cand, chk)                                                                              \
+            if (k < ncand && left) {                                                                                \
+                --left;                                                                                             \
+                bool go = true;                                                                                     \
+                if (best >= 3u) go = (off == best - 3u) ? (chk == mine) : (d32(L, cand + best - 3u) == d32(L, p + best - 3u)); \
+                if (go) {                                                                                           \
+                    uint32_t l = 0;                                                                                 \
+                    while (l < maxl) { /* eight bytes a step */                                                     \
+                        const uint64_t x = d64(L, p + l) ^ d64(L, cand + l);                                        \
+                        if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; break; }                                   \
+                        l += 8u;                                                                                    \
+                    }                                                                                               \
+                    if (l > maxl) l = maxl;                                                                         \
+                    if (l > best) {                                                                                 \
+                        best = l;                                                                                   \
+                        bdist = p - cand;                                                                           \
+                        if (l >= kDfNice || l >= maxl) left = 0u;                                                   \
+                        else if (l >= kDfGood && left > kDfDepth / 4u) left = kDfDepth / 4u;                        \
+                    }                                                                                               \
+                }                                                                                                   \
+            }
+            SNAPHASH_DF_EVAL(0u, c0_, k0) SNAPHASH_DF_EVAL(1u, c1_, k1) SNAPHASH_DF_EVAL(2u, c2_, k2) SNAPHASH_DF_EVAL(3u, c3_, k3)
+#undef SNAPHASH_DF_EVAL
+            if (!(more && left)) { // the walk is over: the position's result
+                if (best == 3u && bdist > kDfTooFar) best = 0u;
+                res[rel] = best >= kDfMinMatch ? res_pack(best, bdist, byte) : res_pack(0u, 0u, byte);
+                active = false;
+            }
+        }
+    }
+}
+
 // ---- parser (waves 1-4): the price parse of one window of a segment (deflate_core.h; tests/deflate_model.h is its
 // serial form).  In: the search results of the segment.  Out: startbits / matchbits / per-tile match counts of its
 // tiles, and in the result word of every position that begins a match the length the parse chose (it may be shorter
@@ -801,6 +902,7 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
             __builtin_amdgcn_s_setprio(0);
         }
         if (chunk_step && j < nseg) {
+#if defined(SNAPHASH_DF_TILE_SEARCH) // round 3's form: a tile per wave at a time, a tile costs its slowest lane
             for (;;) {
                 uint32_t item = 0;
                 if (lane == 0u) item = atomicAdd(&L.queue[1], 1u);
@@ -809,6 +911,9 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
                 STAMP(t_wait, while (__hip_atomic_load(&L.across_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= item) __builtin_amdgcn_s_sleep(1));
                 STAMP(t_sea, L.res[j % 3u][item * 64u + lane] = search_position(L, in, n_in, c0 + (uint64_t)j * kDfSeg + item * 64u + lane, c1));
             }
+#else
+            STAMP(t_sea, search_segment_stream(L, in, n_in, c0 + (uint64_t)j * kDfSeg, c1, L.res[j % 3u], lane));
+#endif
         }
         SYNC_STAMPED(3);
         if (threadIdx.x == 0u) { L.queue[0] = 0u; L.queue[1] = 0u; } // handed out again only behind the next step's barriers

@@ -66,6 +66,19 @@ struct Slot {
     bool busy = false;
 };
 
+// A batch of the hashing engine lives in a sub-slot: a piece of one of the engine's staging buffers with its own job
+// array and events.  A job of several buffers' worth is cut into batches much smaller than a buffer (hash_sources):
+// when the streams' own rate is about the link's (a rank's shard of config 4: 1 250 streams x 44 MB/s = 55 GB/s), fill,
+// copy and kernel are three stages of equal length and only many small batches in flight keep all three busy.
+struct SubSlot {
+    Job* h_jobs = nullptr; // pinned
+    Job* d_jobs = nullptr;
+    size_t jobs_cap = 0;
+    hipEvent_t done = nullptr;   // kernel of the batch staged here has finished
+    hipEvent_t copied = nullptr; // H2D of this batch's jobs has finished
+    bool busy = false;
+};
+
 double now_ms()
 {
     using namespace std::chrono;
@@ -86,6 +99,7 @@ struct DevCtx {
     uint32_t kernel_pref = SNAPHASH_KERNEL_AUTO;
     uint32_t n_xcd = 8; // XCDs (L2 domains) the device presents: 8 in SPX mode; the DEFLATE launch keeps a run of chunks on one
 
+    std::vector<SubSlot> sub; // the hashing engine's batches in flight (pieces of slot[0..2])
     Slot slot[3]; // [0], [1]: every staging user; [2]: a third buffer for the hashing engine alone, allocated when a call
                   // has more than two buffers' worth of bytes (fill k+2 then overlaps kernel k: with two, a job whose
                   // kernels take as long as its copies -- one rank's shard of config 4 -- idles between batches)
@@ -496,12 +510,31 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     std::atomic<int64_t> first_err_src{-1};
     std::vector<ReadOp> ops;
     const bool from_memory = src[0].mem != nullptr;
-    const uint64_t S_full = slot_bytes;
+    const uint64_t seg_floor = from_memory ? kMinSegmentMem : kMinSegment;
+    // The batch: a job of more than a buffer is cut into about two dozen batches (32 MiB at least, a buffer at most, and
+    // room for every stream's floor), each in a sub-slot of the buffers; so many are in flight that the fill runs
+    // ahead of the copy engine and the copy engine ahead of the kernels.
+    uint64_t S_full = slot_bytes;
+    if (job_bytes + kAlign * n > slot_bytes && (slot_bytes & (slot_bytes - 1)) == 0 && slot_bytes > (32u << 20)) {
+        S_full = 32u << 20;
+        while (S_full < slot_bytes && (S_full < job_bytes / 24 || S_full < (seg_floor + kAlign) * std::min<uint64_t>(n, kTargetStreams))) S_full <<= 1;
+    }
+    const unsigned per_slot = (unsigned)(slot_bytes / S_full), nsub = nslots * per_slot;
+    if (c->sub.size() < nsub) c->sub.resize(nsub);
+    for (unsigned q = 0; q < nsub; ++q) {
+        SubSlot& ss = c->sub[q];
+        if (!ss.done) HIP_TRY(c, hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
+        if (!ss.copied) HIP_TRY(c, hipEventCreateWithFlags(&ss.copied, hipEventDisableTiming));
+        ss.busy = false;
+    }
     unsigned batch = 0;
     double t_wait = 0, t_plan = 0, t_read = 0, t_launch = 0; // where the host side of the engine spends its time (SNAPHASH_TRACE_TREE)
 
     while (!active.empty()) {
-        Slot& sl = c->slot[batch % nslots];
+        const unsigned q = batch % nsub;
+        SubSlot& sl = c->sub[q];
+        uint8_t* const sl_h = c->slot[q / per_slot].h_buf + (uint64_t)(q % per_slot) * S_full;
+        uint8_t* const sl_d = c->slot[q / per_slot].d_buf + (uint64_t)(q % per_slot) * S_full;
         const double tb0 = now_ms();
         if (sl.busy) { HIP_TRY(c, hipEventSynchronize(sl.done)); sl.busy = false; }
         const double tb1 = now_ms();
@@ -516,7 +549,6 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         // shard one of eight ranks gets.  A job that fits one slot is one batch.
         long double total_rem = 0;
         for (uint32_t id : active) total_rem += (long double)(src[id].gpu_len - done[id]);
-        const uint64_t seg_floor = from_memory ? kMinSegmentMem : kMinSegment;
         uint64_t S = S_full;
         if (job_bytes + kAlign * n > S_full) {
             if (batch < 3) S = std::max<uint64_t>((S_full >> (3 - batch)) & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20));
@@ -547,13 +579,13 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
             const bool last = take == rem;
             const bool fin = last && src[id].gpu_len == src[id].len;
             Job j;
-            j.data = (uint64_t)(uintptr_t)(sl.d_buf + at);
+            j.data = (uint64_t)(uintptr_t)(sl_d + at);
             j.nbytes = take;
             j.total_prev = done[id];
             j.idx = id;
             j.flags = (done[id] == 0 ? kJobFirst : 0u) | (fin ? kJobFinal : 0u);
             sl.h_jobs[nj++] = j;
-            if (take) ops.push_back(ReadOp{id, done[id], take, sl.h_buf + at, fin && src[id].path != nullptr});
+            if (take) ops.push_back(ReadOp{id, done[id], take, sl_h + at, fin && src[id].path != nullptr});
             used = at + take;
             done[id] += take;
             c->stats.blocks += padded_blocks(take, fin);
@@ -572,7 +604,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
             EventPair* ev = next_events(c, 1);
             if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
             HIP_TRY(c, hipEventRecord(ev->a, c->copy_stream));
-            HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, used, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(c, hipMemcpyAsync(sl_d, sl_h, used, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(c, hipEventRecord(ev->b, c->copy_stream));
         }
         rc = launch_jobs(c, sl.h_jobs, sl.d_jobs, nj, c->d_digests, sl.copied);
@@ -588,7 +620,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     if (getenv("SNAPHASH_TRACE_TREE"))
         fprintf(stderr, "snaphash engine %d: %u batches; waiting for a slot %.1f ms, planning %.1f ms, reads %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
                 c->index, batch, t_wait, t_plan, t_read, t_launch, now_ms() - ts0);
-    for (Slot& sl : c->slot) sl.busy = false;
+    for (SubSlot& ss : c->sub) ss.busy = false;
     if (rc) return rc;
     if (first_err.load()) {
         const int64_t s = first_err_src.load();
@@ -1039,6 +1071,12 @@ static void destroy_dev(DevCtx* c)
         if (s.d_jobs) (void)hipFree(s.d_jobs);
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.copied) (void)hipEventDestroy(s.copied);
+    }
+    for (SubSlot& q : c->sub) {
+        if (q.h_jobs) (void)hipHostFree(q.h_jobs);
+        if (q.d_jobs) (void)hipFree(q.d_jobs);
+        if (q.done) (void)hipEventDestroy(q.done);
+        if (q.copied) (void)hipEventDestroy(q.copied);
     }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_chunks) (void)hipHostFree(c->h_chunks);

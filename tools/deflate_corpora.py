@@ -72,5 +72,6 @@ with Context() as c:
         t6 = time.perf_counter() - t0
         z9 = len(zlib.compress(sample, 9)) / len(sample)
         gs = len(c.gzip_buffer(sample)) / len(sample)
-        print("%-28s kernel %.1f ms per 64 MiB = %.2f GB/s; ratio %.4f (first 8 MiB: %.4f; zlib -6 %.4f at %.0f MB/s on one core, zlib -9 %.4f)" %
-              (name, best, len(data) / best / 1e6, len(gz) / len(data), gs, z6, len(sample) / t6 / 1e6, z9), flush=True)
+        import hashlib
+        print("%-28s kernel %.1f ms per 64 MiB = %.2f GB/s; ratio %.4f (first 8 MiB: %.4f; zlib -6 %.4f at %.0f MB/s on one core, zlib -9 %.4f); sha256 of the output %s" %
+              (name, best, len(data) / best / 1e6, len(gz) / len(data), gs, z6, len(sample) / t6 / 1e6, z9, hashlib.sha256(gz).hexdigest()[:16]), flush=True)

@@ -317,14 +317,16 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     return best >= kDfMinMatch ? res_pack(best, bdist, byte) : res_pack(0u, 0u, byte);
 }
 
-// ---- searcher, round 4: the lanes of a wave STREAM through positions -----------------------------------------------
-// search_position above gives a wave one tile and the tile costs what its slowest lane costs: on content with long
-// matches a few lanes walk 8 batches while most are done after one or two, and 60 % of the issue slots go to waiting
-// (sources: 17.0 ms per 64 MiB against 10.2 for text).  Here a lane that is done with its position takes
-// the next one of the wave's pool (a tile from the step's queue, as before) at the top of the next batch: the wave stays
-// full until the queue is empty, and a step costs the lanes' average instead of a maximum per tile.  The walk of a
-// position -- batches of four links, check words, extensions, the serial walk's exact result -- is unchanged, so the
-// bytes still equal those of the serial model (tests/deflate_model.h).
+// ---- searcher, round 4 experiment (make stream; MEASURED SLOWER, profiles/r04_deflate_stream_search.txt): the lanes of a
+// wave STREAM through positions.  search_position above gives a wave one tile and the tile costs what its slowest lane
+// costs: on content with long matches a few lanes walk 8 batches while most are done after one or two (sources: 17 ms per
+// 64 MiB against 10 for text).  Here a lane that is done with its position takes the next one of the
+// wave's pool (a tile from the step's queue, as before) at the top of the next batch: the wave stays full until the queue
+// is empty, and a step costs the lanes' average instead of a maximum per tile.  The walk of a position is unchanged and the
+// output is byte for byte the same -- and the kernel is 10-20 % SLOWER on all three corpora (12.1 / 18.9 / 12.3 ms against
+// 10.0 / 16.8 / 11.4): in a tile adjacent lanes hold adjacent positions, whose chains visit adjacent candidates (one
+// cache line of check words, neighbouring LDS banks), and a wave of unrelated positions gives that up for its fuller lanes.
+#if defined(SNAPHASH_DF_STREAM_SEARCH)
 __device__ __forceinline__ void search_segment_stream(ChunkLds& L, const uint8_t* __restrict__ in, uint64_t n_in, uint64_t seg64, uint64_t c1,
                                                       uint32_t* __restrict__ res, uint32_t lane)
 {
@@ -417,6 +419,7 @@ __device__ __forceinline__ void search_segment_stream(ChunkLds& L, const uint8_t
         }
     }
 }
+#endif // SNAPHASH_DF_STREAM_SEARCH
 
 // ---- parser (waves 1-4): the price parse of one window of a segment (deflate_core.h; tests/deflate_model.h is its
 // serial form).  In: the search results of the segment.  Out: startbits / matchbits / per-tile match counts of its
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
             __builtin_amdgcn_s_setprio(0);
         }
         if (chunk_step && j < nseg) {
-#if defined(SNAPHASH_DF_TILE_SEARCH) // round 3's form: a tile per wave at a time, a tile costs its slowest lane
+#if !defined(SNAPHASH_DF_STREAM_SEARCH) // a tile per wave at a time: a tile costs its slowest lane, and adjacent positions walk adjacent candidates
             for (;;) {
                 uint32_t item = 0;
                 if (lane == 0u) item = atomicAdd(&L.queue[1], 1u);

@@ -13,6 +13,7 @@
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -140,6 +141,7 @@ struct DevCtx {
     std::string pci_bus_id;
     int numa_node = -1;        // -1: unknown or not applied (single-node host, SNAPHASH_FLAG_NO_NUMA)
     int staging_node = -1;     // node the first staging page was found on after allocation (diagnostic)
+    int64_t fd_budget = 0;     // file descriptors a hashing call may keep open between batches (FdCache)
     unsigned fill_cap = 12;    // most fill threads this engine uses (the ctx divides the usable CPUs among its engines)
     FillPool pool;
 
@@ -420,14 +422,38 @@ struct Source {
 
 struct ReadOp { uint32_t src; uint64_t off; uint64_t n; uint8_t* dst; bool to_eof; };
 
+// Descriptors a hashing call keeps open between the batches a file appears in: a file of several batches is opened once,
+// not once per segment (10 001 x 1 MiB in 64 KiB segments: 160 000 open/close pairs, a third of the fill threads' time).
+// A stream has one read operation per batch and batches are filled one after the other, so a slot is touched by one
+// thread at a time.  budget: descriptors this engine may hold (RLIMIT_NOFILE, shared among engines); beyond it a
+// segment opens and closes its file as before.
+struct FdCache {
+    std::vector<int> fd;            // per source, -1 = not open
+    std::atomic<int64_t> held{0};
+    int64_t budget = 0;
+    explicit FdCache(size_t n, int64_t b) : fd(n, -1), budget(b) {}
+    ~FdCache() { for (int f : fd) if (f >= 0) close(f); }
+    FdCache(const FdCache&) = delete;
+    FdCache& operator=(const FdCache&) = delete;
+};
+
 // One read operation of a staging fill: file source -> open + pread (io.Copy's semantics: a file that shrank or
 // grew since its size was taken is an error), memory source -> a streaming copy.  Returns 0 or an errno.
-int do_read_op(const Source& s, const ReadOp& op)
+int do_read_op(const Source& s, const ReadOp& op, FdCache* cache = nullptr)
 {
     if (s.mem) { copy_to_staging(op.dst, s.mem + op.off, op.n); return 0; }
     int err = 0;
-    int fd = open(s.path, O_RDONLY | O_CLOEXEC);
-    if (fd < 0) err = errno;
+    int fd = cache ? cache->fd[op.src] : -1;
+    bool cached = fd >= 0;
+    if (fd < 0) {
+        fd = open(s.path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) err = errno;
+        else if (cache && !op.to_eof && cache->held.load(std::memory_order_relaxed) < cache->budget) { // more segments will follow
+            cache->fd[op.src] = fd;
+            cache->held.fetch_add(1, std::memory_order_relaxed);
+            cached = true;
+        }
+    }
     uint64_t got = 0;
     while (!err && got < op.n) {
         ssize_t r = pread(fd, op.dst + got, op.n - got, (off_t)(op.off + got));
@@ -442,13 +468,16 @@ int do_read_op(const Source& s, const ReadOp& op)
         if (r > 0) err = EIO;
         else if (r < 0) err = errno;
     }
-    if (fd >= 0) close(fd);
+    if (fd >= 0 && (!cached || op.to_eof || err)) { // the stream's last segment (or an error) closes a kept descriptor
+        close(fd);
+        if (cached) { cache->fd[op.src] = -1; cache->held.fetch_sub(1, std::memory_order_relaxed); }
+    }
     return err;
 }
 
 // Fills a staging slot: the engine's pool of fill threads (on the GPU's NUMA node, hostfill.h) runs the operations.
 void run_reads(DevCtx* c, const std::vector<Source>& src, const std::vector<ReadOp>& ops, std::atomic<int>& first_err,
-               std::atomic<int64_t>& first_err_src)
+               std::atomic<int64_t>& first_err_src, FdCache* cache = nullptr)
 {
     // Staging-fill threads, measured on the GPU box (tools/copy_threads_sweep.sh): copies from caller memory
     // peak at 6 threads (44 GiB/s end to end; 16 threads: 33 -- they fight the concurrent H2D DMA for host
@@ -465,7 +494,7 @@ void run_reads(DevCtx* c, const std::vector<Source>& src, const std::vector<Read
     c->pool.parallel_for(ops.size(), T, [&](size_t i) {
         if (first_err.load(std::memory_order_relaxed)) return;
         const ReadOp& op = ops[i];
-        const int err = do_read_op(src[op.src], op);
+        const int err = do_read_op(src[op.src], op, cache);
         if (err) {
             int z = 0;
             if (first_err.compare_exchange_strong(z, err)) first_err_src.store(op.src);
@@ -510,6 +539,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     std::atomic<int64_t> first_err_src{-1};
     std::vector<ReadOp> ops;
     const bool from_memory = src[0].mem != nullptr;
+    FdCache fds(from_memory ? 0 : n, c->fd_budget);
     const uint64_t seg_floor = from_memory ? kMinSegmentMem : kMinSegment;
     // The batch: a job of more than a buffer is cut into about two dozen batches (32 MiB at least, a buffer at most, and
     // room for every stream's floor), each in a sub-slot of the buffers; so many are in flight that the fill runs
@@ -595,7 +625,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         const double tb2 = now_ms();
         t_plan += tb2 - tb1;
 
-        run_reads(c, src, ops, first_err, first_err_src);
+        run_reads(c, src, ops, first_err, first_err_src, from_memory ? nullptr : &fds);
         if (first_err.load()) break;
         const double tb3 = now_ms();
         t_read += tb3 - tb2;
@@ -1164,6 +1194,23 @@ try {
     const std::string sysfs = sysfs_env && *sysfs_env ? sysfs_env : "/sys";
     const bool numa_on = !(x->flags & SNAPHASH_FLAG_NO_NUMA) && numa_node_count(sysfs) > 1;
     const unsigned fill_cap = std::max(2u, std::min(12u, ncpu / (unsigned)devs.size()));
+    // Descriptors the engines may keep open between batches (FdCache): what RLIMIT_NOFILE leaves after a reserve for the
+    // application, shared among the engines.  The soft limit is raised to the hard one first (at most 65 536), as the Go
+    // runtime itself does at start-up since 1.19: a tree of 10 000 files would otherwise be opened segment by segment.
+    int64_t fd_budget = 0;
+    {
+        struct rlimit rl;
+        if (getrlimit(RLIMIT_NOFILE, &rl) == 0) {
+            const rlim_t want = rl.rlim_max == RLIM_INFINITY ? 65536 : std::min<rlim_t>(rl.rlim_max, 65536);
+            if (rl.rlim_cur != RLIM_INFINITY && rl.rlim_cur < want) {
+                struct rlimit up = rl;
+                up.rlim_cur = want;
+                if (setrlimit(RLIMIT_NOFILE, &up) == 0) rl = up;
+            }
+            const int64_t soft = rl.rlim_cur == RLIM_INFINITY ? 65536 : (int64_t)rl.rlim_cur;
+            fd_budget = std::max<int64_t>(0, std::min<int64_t>(soft - 512, 32768)) / (int64_t)devs.size();
+        }
+    }
     for (size_t k = 0; k < devs.size(); ++k) {
         const int dev = devs[k];
         if (dev < 0 || dev >= ndev) {
@@ -1198,6 +1245,7 @@ try {
         if (!rc) {
             if (c->staging < (1u << 16)) c->staging = 1u << 16;
             c->fill_cap = fill_cap;
+            c->fd_budget = fd_budget;
             { // SPX: 8; a CPX/DPX partition presents fewer
                 int xcc = 0;
                 if (hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && xcc >= 1 && xcc <= 64) c->n_xcd = (uint32_t)xcc;

@@ -49,7 +49,8 @@ namespace {
 
 constexpr uint64_t kDefaultStaging = 256ull << 20;
 constexpr uint64_t kAlign = 256;          // placement of a segment inside a staging buffer
-constexpr uint64_t kMinSegment = 64u << 10;    // least a FILE stream is given of a slot, unless it ends there (an open + close per segment)
+constexpr uint64_t kMinSegment = 32u << 10;    // least a FILE stream is given of a slot, unless it ends there (a pread per segment; an open + close
+                                               // too once the call holds more descriptors than its budget, FdCache)
 constexpr uint64_t kMinSegmentMem = 16u << 10; // the same for a stream in caller memory (a copy has no such cost)
 constexpr uint32_t kTargetStreams = 4096; // streams per batch the engine aims for (keeps the kernel ahead of PCIe)
 
@@ -1569,7 +1570,8 @@ void snaphash_free(void* p) { free(p); }
 // turns the gathered slabs into hashes.yaml.  plan and emit are host-only.
 struct snaphash_shard {
     std::vector<Record> recs;
-    std::vector<std::string> all_paths;       // stream i of the whole job: [0] = the archive, then the regular files in walk order
+    std::string tar_path;
+    std::vector<const char*> all_paths;       // stream i of the whole job: [0] = the archive, then the regular files in walk order (into recs / tar_path)
     std::vector<int64_t> all_sizes;
     std::vector<int32_t> shard_of;            // per stream
     std::vector<uint32_t> row_of;             // per stream: its row in its rank's slab
@@ -1591,14 +1593,19 @@ try {
     sh->rank = rank;
     sh->world = world;
     int en = 0;
+    const double tp0 = now_ms();
     int rc = walk_tree(build_dir, sh->recs, &en);
     if (rc) { errno = en; return rc; }
+    const double tp1 = now_ms();
     for (const Record& r : sh->recs)
         if (!name_emittable(r.name)) return SNAPHASH_ENAME;
-    sh->all_paths.push_back(data_tar);
+    sh->tar_path = data_tar;
+    sh->all_paths.reserve(sh->recs.size() + 1);
+    sh->all_sizes.reserve(sh->recs.size() + 1);
+    sh->all_paths.push_back(sh->tar_path.c_str());
     sh->all_sizes.push_back((int64_t)st.st_size);
-    for (const Record& r : sh->recs)
-        if (r.is_regular) { sh->all_paths.push_back(r.path); sh->all_sizes.push_back(r.size); }
+    for (const Record& r : sh->recs) // (recs is not touched again: the pointers stay good)
+        if (r.is_regular) { sh->all_paths.push_back(r.path.c_str()); sh->all_sizes.push_back(r.size); }
     const size_t n = sh->all_paths.size();
     std::vector<uint64_t> lens(n);
     for (size_t i = 0; i < n; ++i) lens[i] = (uint64_t)sh->all_sizes[i];
@@ -1612,10 +1619,12 @@ try {
     for (size_t i = 0; i < n; ++i)
         if ((uint32_t)sh->shard_of[i] == rank) {
             sh->mine.push_back((uint32_t)i);
-            sh->my_paths.push_back(sh->all_paths[i].c_str());
+            sh->my_paths.push_back(sh->all_paths[i]);
             sh->my_sizes.push_back(i == 0 ? -1 : sh->all_sizes[i]); // the archive's length is taken when it is read, like snaphash_tree
             sh->my_bytes += lens[i];
         }
+    if (getenv("SNAPHASH_TRACE_TREE"))
+        fprintf(stderr, "snaphash shard plan: walk %.2f ms (%zu records), names + lists + LPT over %u ranks %.2f ms\n", tp1 - tp0, sh->recs.size(), world, now_ms() - tp1);
     *out = sh.release();
     return SNAPHASH_OK;
 } catch (...) {

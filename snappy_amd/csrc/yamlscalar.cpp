@@ -448,6 +448,7 @@ int yaml_append_name_scalar(const std::string& s, int column, int indent, std::s
 
 bool name_emittable(const std::string& s)
 {
+    if (plain_safe_name(s)) return true; // the pinned case, as the emitter short-cuts it (hostpass.cpp emit_yaml)
     std::string tmp;
     return yaml_append_name_scalar(s, 7, 4, tmp) == SNAPHASH_OK;
 }

@@ -23,13 +23,30 @@ os.makedirs(out, exist_ok=True)
 ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(out, tag + "_kernel_stats.csv"))
+# The default command launches the hashing kernel two ways: ONE launch over the whole resident tree (the roofline object:
+# 157 workgroups for 10 001 streams) and the staged batches of the end-to-end pass (4 096 streams = 64 workgroups each).
+# rocprofv3's --stats averages them under one name; the per-launch trace separates them by grid size.
+kt = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+if kt:
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt[0])):
+        if "sha512" in r["Kernel_Name"] or "deflate" in r["Kernel_Name"]:
+            groups[(r["Kernel_Name"], r["Grid_Size"], r["Workgroup_Size"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    with open(os.path.join(out, tag + "_kernel_by_grid.csv"), "w") as f:
+        f.write("kernel,grid_size,workgroup_size,calls,avg_ms,min_ms,max_ms\n")
+        for (k, g, w), v in sorted(groups.items(), key=lambda kv: -max(kv[1])):
+            f.write('"%s",%s,%s,%d,%.4f,%.4f,%.4f\n' % (k, g, w, len(v), sum(v) / len(v), min(v), max(v)))
 pmc = {}
 kname = None
+resident_grid = None
+if kt:
+    big = [(max(v), g) for (k, g, w), v in groups.items() if "sha512" in k]
+    resident_grid = max(big)[1] if big else None
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "sha512" in r["Kernel_Name"]:
+            if "sha512" in r["Kernel_Name"] and (resident_grid is None or r["Grid_Size"] == resident_grid):  # the resident launch only
                 kn = r["Kernel_Name"]
                 kname = ("sha512_split_kernel_true" if "<true>" in kn or "ILb1" in kn else "sha512_split_kernel_false") if "split" in kn else "sha512_wide_kernel"
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -389,7 +389,7 @@ typedef struct snaphash_plan_model {
     uint32_t from_files;     /* sources are paths rather than caller memory */
     double host_rate;        /* B/s, one host core's SHA-512 (0 = 1.4e9) */
     double gpu_stream_rate;  /* B/s, ONE stream under the lane-pair kernel (0 = 44e6) */
-    double gpu_link;         /* B/s, one engine's staging + PCIe copy (0 = 54e9 memory, 48e9 files) */
+    double gpu_link;         /* B/s, one engine's staging + PCIe copy (0 = 55e9 memory, 54e9 files) */
     double gpu_latency;      /* s per launch whatever its size (0 = 150e-6) */
     /* out */
     double gpu_seconds;      /* modelled makespan of the GPU part (0 = none) */

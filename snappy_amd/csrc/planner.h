@@ -24,7 +24,7 @@ struct PlanModel {
     double host_per_stream = 0;   // s per stream on a host thread; 0 = 4 us for files, 0.05 us for memory
     double gpu_pair_rate = 44e6;  // B/s of ONE stream under the lane-pair kernel (few, long streams)
     double gpu_wide_rate = 18e6;  // B/s of ONE stream under the lane-per-stream kernel
-    double gpu_link = 0;          // B/s one engine stages and copies (PCIe inclusive); 0 = 54e9 memory, 48e9 files
+    double gpu_link = 0;          // B/s one engine stages and copies (PCIe inclusive); 0 = 55e9 memory, 54e9 files (measured end to end, r04)
     double gpu_latency = 150e-6;  // s a launch costs whatever its size: job upload, kernel start, sync, digests back
     double gpu_per_stream = 0;    // s per stream of planning + fill on the GPU side; 0 = 0.15 us memory, 0.5 us files
 };

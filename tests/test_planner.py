@@ -83,8 +83,10 @@ def test_few_huge_streams_go_to_the_host_whole(built_lib):
 def test_explicit_thread_count_and_more_cores(built_lib):
     lens = [MiB] * 10001
     _, r4 = _plan(lens, host_threads=4)
+    _, r8 = _plan(lens, host_threads=8)
     _, r32 = _plan(lens, host_threads=32)
-    assert r4["host_threads"] == 4 and r32["host_threads"] == 32 and r32["host_bytes"] > r4["host_bytes"]
+    # a link-bound batch is split only for a modelled 10 % or more (profiles/r04_default_probe.txt): four threads add 9 %
+    assert r4["host_bytes"] == 0 and r8["host_threads"] == 8 and r32["host_threads"] == 32 and r32["host_bytes"] > r8["host_bytes"] > 0
     _, one = _plan(lens, cpus=1)  # nothing to spare beside the staging fill: one thread helps a little or not at all
     assert one["host_bytes"] < 0.05 * sum(lens)
 

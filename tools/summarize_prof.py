@@ -31,7 +31,7 @@ if kt:
     groups = collections.defaultdict(list)
     for r in csv.DictReader(open(kt[0])):
         if "sha512" in r["Kernel_Name"] or "deflate" in r["Kernel_Name"]:
-            groups[(r["Kernel_Name"], r["Grid_Size"], r["Workgroup_Size"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            groups[(r["Kernel_Name"], r["Grid_Size_X"], r["Workgroup_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     with open(os.path.join(out, tag + "_kernel_by_grid.csv"), "w") as f:
         f.write("kernel,grid_size,workgroup_size,calls,avg_ms,min_ms,max_ms\n")
         for (k, g, w), v in sorted(groups.items(), key=lambda kv: -max(kv[1])):

@@ -9,7 +9,7 @@ import stat
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 import trees
 
 pytestmark = pytest.mark.gpu
@@ -469,6 +469,29 @@ def test_eight_engines_in_one_process(built_lib, oracle):
         assert got8[64 * i:64 * i + 64] == oracle.sha512(host[int(off[i]):int(off[i]) + (1 << 20)].tobytes())
     print("eight engines on one GPU: %d x 1 MiB in %.1f ms (one engine: %.1f ms); pinned %.2f GiB, HBM %.2f GiB; CPU slices %s" %
           (n, t8 * 1e3, t1 * 1e3, sum(e["pinned_bytes"] for e in infos) / 2**30, hbm / 2**30, [len(s) for s in cpus]))
+
+
+def test_descriptor_budget_smaller_than_the_tree(built_lib, oracle, tmp_path):
+    """The engine keeps a file's descriptor between the batches the file appears in (FdCache) only within what
+    RLIMIT_NOFILE leaves: with a budget far below the number of files the rest is opened segment by segment, as round 3
+    did, and nothing changes but the speed.  Run in a child process (the limit is per process)."""
+    import subprocess
+    import sys
+    sizes = [int(x) for x in _ragged_sizes(700, 31, 1 << 18)] + [3 << 20, 1 << 20, 5]
+    build, tar = trees.make_synthetic_tree(str(tmp_path), sizes)
+    want = oracle.hashes_yaml(build, tar)
+    code = (
+        "import resource, sys\n"
+        "resource.setrlimit(resource.RLIMIT_NOFILE, (560, 560))\n"   # budget = 560 - 512 = 48 descriptors for 702 files
+        "sys.path.insert(0, %r)\n"
+        "from snappy_amd import Context, _lib\n"
+        "with Context(staging_bytes=4 << 20, flags=_lib.FLAG_GPU_ONLY) as c:\n"   # 4 MiB staging: every file of any size spans batches
+        "    y = c.tree(%r, %r)\n"
+        "    assert c.stats()['launches'] > 8\n"
+        "sys.stdout.buffer.write(y)\n" % (ROOT, build, tar))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-800:]
+    assert r.stdout == want
 
 
 def test_engine_info_and_numa_flags(built_lib):

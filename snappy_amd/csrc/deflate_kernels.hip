@@ -256,6 +256,44 @@ __device__ __forceinline__ void index_segment_across(ChunkLds& L, uint64_t n_in,
     }
 }
 
+// How many bytes at cand equal those at p (at most maxl).  The first eight alone -- most candidates of prose end there --
+// then THIRTY-TWO a step: the four 8-byte compares of a step are independent, so a step costs one LDS round trip where
+// round 3's eight-bytes-a-step loop cost four, and the walk is bound by exactly those round trips (a wave issues an
+// instruction every ~6 cycles with four waves per SIMD: it waits).  Reads run up to 31 bytes past the match's end: inside
+// the data ring (the look-ahead covers 258 + 8; what lies beyond only ever raises a length that is cut to maxl).
+#if !defined(SNAPHASH_DF_NARROW_EXTEND)
+__device__ __forceinline__ uint32_t extend_match(const ChunkLds& L, uint32_t p, uint32_t cand, uint32_t maxl)
+{
+    const uint64_t x0 = d64(L, p) ^ d64(L, cand);
+    if (x0) { const uint32_t l = (uint32_t)__builtin_ctzll(x0) >> 3; return l < maxl ? l : maxl; }
+    uint32_t l = 8u;
+    while (l < maxl) {
+        const uint64_t a0 = d64(L, p + l) ^ d64(L, cand + l), a1 = d64(L, p + l + 8u) ^ d64(L, cand + l + 8u),
+                       a2 = d64(L, p + l + 16u) ^ d64(L, cand + l + 16u), a3 = d64(L, p + l + 24u) ^ d64(L, cand + l + 24u);
+        if ((a0 | a1) | (a2 | a3)) {
+            if (a0) l += (uint32_t)__builtin_ctzll(a0) >> 3;
+            else if (a1) l += 8u + ((uint32_t)__builtin_ctzll(a1) >> 3);
+            else if (a2) l += 16u + ((uint32_t)__builtin_ctzll(a2) >> 3);
+            else l += 24u + ((uint32_t)__builtin_ctzll(a3) >> 3);
+            break;
+        }
+        l += 32u;
+    }
+    return l < maxl ? l : maxl;
+}
+#else // round 3's form, for A/B (make narrow)
+__device__ __forceinline__ uint32_t extend_match(const ChunkLds& L, uint32_t p, uint32_t cand, uint32_t maxl)
+{
+    uint32_t l = 0;
+    while (l < maxl) { // eight bytes a step
+        const uint64_t x = d64(L, p + l) ^ d64(L, cand + l);
+        if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; break; }
+        l += 8u;
+    }
+    return l < maxl ? l : maxl;
+}
+#endif
+
 // ---- searcher: the best match of one position ------------------------------------------------------------------
 __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uint8_t* __restrict__ in, uint64_t n_in, uint64_t p64, uint64_t c1)
 {
@@ -295,13 +333,7 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
             bool go = true;                                                                                     \
             if (best >= 3u) go = (off == best - 3u) ? (chk == mine) : (d32(L, cand + best - 3u) == d32(L, p + best - 3u)); \
             if (go) {                                                                                           \
-                uint32_t l = 0;                                                                                 \
-                while (l < maxl) { /* eight bytes a step */                                                     \
-                    const uint64_t x = d64(L, p + l) ^ d64(L, cand + l);                                        \
-                    if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; break; }                                   \
-                    l += 8u;                                                                                    \
-                }                                                                                               \
-                if (l > maxl) l = maxl;                                                                         \
+                const uint32_t l = extend_match(L, p, cand, maxl);                                              \
                 if (l > best) {                                                                                 \
                     best = l;                                                                                   \
                     bdist = p - cand;                                                                           \
@@ -394,13 +426,7 @@ __device__ __forceinline__ void search_segment_stream(ChunkLds& L, const uint8_t
                 bool go = true;                                                                                     \
                 if (best >= 3u) go = (off == best - 3u) ? (chk == mine) : (d32(L, cand + best - 3u) == d32(L, p + best - 3u)); \
                 if (go) {                                                                                           \
-                    uint32_t l = 0;                                                                                 \
-                    while (l < maxl) { /* eight bytes a step */                                                     \
-                        const uint64_t x = d64(L, p + l) ^ d64(L, cand + l);                                        \
-                        if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; break; }                                   \
-                        l += 8u;                                                                                    \
-                    }                                                                                               \
-                    if (l > maxl) l = maxl;                                                                         \
+                    const uint32_t l = extend_match(L, p, cand, maxl);                                              \
                     if (l > best) {                                                                                 \
                         best = l;                                                                                   \
                         bdist = p - cand;                                                                           \

@@ -986,7 +986,9 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
         return bad_rc;
     }
 
-    if (!keep_on_device) {
+    if (!gpu_part) {
+        // every stream went to a host thread: the digests are where they belong already, nothing to gather
+    } else if (!keep_on_device) {
         for (size_t k = 0; k < member[0].size(); ++k) memcpy(digests + 64 * (size_t)member[0][k], job[0].dig.data() + 64 * k, 64);
     } else {
         std::vector<size_t> cnt(nd);

@@ -7,8 +7,12 @@
 #include <errno.h>
 #include <string.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 namespace snaphash {
@@ -145,7 +149,10 @@ int walk_entries(const char* root_c, std::vector<WalkEntry>& ents, int* err_no, 
     ents[0].have_st = true;
     int dir_errno = 0;
     int64_t dir_bad = -1; // entry whose children could not be listed, or whose look-ahead Lstat failed
+    const bool trace = getenv("SNAPHASH_TRACE_TREE") != nullptr;
+    const auto t_list0 = std::chrono::steady_clock::now();
     if (S_ISDIR(ents[0].st.st_mode)) dir_bad = walk_names(root, ents, &dir_errno);
+    const auto t_list1 = std::chrono::steady_clock::now();
 
     const size_t n = ents.size();
     const unsigned T = walk_threads(n, 512);
@@ -164,6 +171,11 @@ int walk_entries(const char* root_c, std::vector<WalkEntry>& ents, int* err_no, 
         for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work, t);
         work(0);
         th.join_all();
+    }
+    if (trace) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "snaphash walk: names (list + sort + pre-order) %.2f ms, Lstat of %zu entries on %u threads %.2f ms\n",
+                std::chrono::duration<double, std::milli>(t_list1 - t_list0).count(), n, T, std::chrono::duration<double, std::milli>(t2 - t_list1).count());
     }
     int64_t first_bad = -1;
     int first_errno = 0;

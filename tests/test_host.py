@@ -378,3 +378,32 @@ def test_numa_probe_on_a_fake_sysfs(built_lib, tmp_path):
     assert _lib.numa_probe(str(sysfs), "0000:aa:00.0") == (-1, [])   # sysfs says "no node"
     assert _lib.numa_probe(str(sysfs), "0000:bb:00.0") == (-1, [])   # unknown function
     assert _lib.numa_probe("/nonexistent", gpus[0]) == (-1, [])
+
+
+def test_large_tree_is_walked_and_written_in_parallel_like_the_serial_loop(built_lib, oracle, tmp_path):
+    """9 000 records: the walk lists the directories of a level on several threads and Lstats in ranges, the emitter
+    writes ranges of records on several threads and joins them in order -- the bytes must be what the oracle's serial
+    loop writes (walk order, digests attached to the right records across the range boundaries, odd names included)."""
+    import hashlib
+    from snappy_amd import _lib
+    b = tmp_path / "build"
+    (b / "DEBIAN").mkdir(parents=True)
+    (b / "DEBIAN" / "control").write_text("x")
+    n = 0
+    for d in range(60):
+        sub = b / ("dir%03d" % d) / ("s%d" % (d % 3))
+        sub.mkdir(parents=True)
+        for k in range(150):
+            name = ("f%04d.bin" % k) if k % 37 else ("odd name %d: [x]" % k)  # quoted scalars in the middle of a range
+            (sub / name).write_bytes(b"%d/%d" % (d, k) if k % 11 else b"")
+            n += 1
+        if d % 7 == 0:
+            os.symlink("f0001.bin", str(sub / "ln"))
+    tar = tmp_path / "data.tar.gz"
+    tar.write_bytes(b"archive")
+    want = oracle.hashes_yaml(str(b), str(tar))
+    recs = _lib.walk(str(b))
+    assert len(recs) > 9000 and sum(1 for r in recs if r["is_regular"]) == n
+    digs = [hashlib.sha512(open(r["path"], "rb").read()).digest() for r in recs if r["is_regular"]]
+    got = _lib.emit_yaml(str(b), hashlib.sha512(b"archive").digest(), digs)
+    assert got == want

@@ -61,29 +61,36 @@ int mode_parse(const char* s, uint32_t* st_mode)
 
 // The records of the entries writeHashes' callback keeps (walk.h gives the entries in Walk's order with their Lstat).
 // SNAPHASH_EMODE for the first entry whose type yamlFileMode cannot express (hashes.go:33-57).
-int records_from_entries(const std::vector<WalkEntry>& ents, std::vector<Record>& out)
+// steal: the entries' path strings move into the records (the caller is done with the entries)
+static int records_from_entries_impl(std::vector<WalkEntry>& ents, std::vector<Record>& out, bool steal)
 {
     if (ents.empty()) return SNAPHASH_OK;
     const size_t rootlen = ents[0].path.size();
     out.reserve(out.size() + ents.size());
-    for (const WalkEntry& e : ents) {
+    for (WalkEntry& e : ents) {
         const char* rel = e.path.c_str() + rootlen;
         // build.go:229: string prefix, not path component -- "/DEBIAN-extra" is skipped too;
         // build.go:232: the root itself.  The callback returns nil (not SkipDir), so
         // Walk still descends into DEBIAN and skips its children one by one.
         const bool skip = rel[0] == 0 || strncmp(rel, "/DEBIAN", 7) == 0;
         if (skip) continue;
-        Record r;
-        r.name = rel + 1; // build.go:250
-        r.path = e.path;
+        char m[11];
+        if (mode_string(e.st.st_mode, m) != SNAPHASH_OK) return SNAPHASH_EMODE;
+        out.emplace_back();
+        Record& r = out.back();
+        r.name.assign(rel + 1, e.path.size() - rootlen - 1); // build.go:250
         r.st_mode = e.st.st_mode;
         r.is_regular = S_ISREG(e.st.st_mode); // build.go:240
         r.size = r.is_regular ? (int64_t)e.st.st_size : 0;
-        char m[11];
-        if (mode_string(e.st.st_mode, m) != SNAPHASH_OK) return SNAPHASH_EMODE;
-        out.push_back(std::move(r));
+        if (steal) r.path = std::move(e.path);
+        else r.path = e.path;
     }
     return SNAPHASH_OK;
+}
+
+int records_from_entries(const std::vector<WalkEntry>& ents, std::vector<Record>& out)
+{
+    return records_from_entries_impl(const_cast<std::vector<WalkEntry>&>(ents), out, false);
 }
 
 int walk_tree(const char* build_dir, std::vector<Record>& out, int* err_no)
@@ -92,7 +99,7 @@ int walk_tree(const char* build_dir, std::vector<Record>& out, int* err_no)
     int e = 0;
     const int wrc = walk_entries(build_dir, ents, &e, nullptr);
     if (err_no) *err_no = e;
-    const int rc = records_from_entries(ents, out); // what was visited before a failure may already hold the first error
+    const int rc = records_from_entries_impl(ents, out, true); // what was visited before a failure may already hold the first error
     if (rc) return rc;
     return wrc ? SNAPHASH_EIO : SNAPHASH_OK;
 }

@@ -34,6 +34,9 @@
  *     inside the library (one host thread and one staging engine per device) and
  *     the digest vector is gathered with a single-process RCCL all-gather over
  *     xGMI.  No signal handlers are installed (the Go runtime owns them).
+ *   - Process-wide effects: snaphash_init raises the soft RLIMIT_NOFILE to the hard limit (at most 65 536, as the Go
+ *     runtime itself does at start-up) so that a hashing call can keep a file's descriptor open between the batches the
+ *     file appears in; the calling thread's memory policy and CPU affinity are left as they were found.
  *   - Digests are raw 64-byte big-endian SHA-512 values; the Go wrapper
  *     hex-encodes them with encoding/hex (lowercase, helpers.go:200).
  */

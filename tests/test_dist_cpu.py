@@ -139,3 +139,46 @@ def test_sharded_tree_world_one_equals_the_plain_emitter(built_lib, oracle, tmp_
         ShardedTree(build, tar + ".missing", 0, 1)
     with pytest.raises(_lib.SnaphashError):
         ShardedTree(build, tar, 2, 2)
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_sharded_tree_edge_shapes_without_a_collective(world, built_lib, oracle, tmp_path):
+    """More ranks than streams, an empty tree (files: []), a tree of directories and symlinks only, zero-length files:
+    every rank's plan is made in this one process, the slabs are laid rank-major by hand, and any rank's emit must write
+    the oracle's hashes.yaml.  (ABI 4 snaphash_shard_plan / _emit are host-only.)"""
+    import hashlib
+    from snappy_amd.sharded import ShardedTree
+
+    def run(build, tar):
+        sts = [ShardedTree(build, tar, r, world) for r in range(world)]
+        try:
+            rows = sts[0].rows
+            assert all(st.rows == rows and st.streams == sts[0].streams for st in sts)
+            assert sum(st.count for st in sts) == sts[0].streams
+            slabs = np.zeros((world * rows, 64), dtype=np.uint8)
+            for r, st in enumerate(sts):
+                for k, p in enumerate(st.paths()):
+                    slabs[r * rows + k] = np.frombuffer(hashlib.sha512(open(p, "rb").read()).digest(), dtype=np.uint8)
+            want = oracle.hashes_yaml(build, tar)
+            for st in sts:
+                assert st.emit(slabs) == want
+        finally:
+            for st in sts:
+                st.close()
+
+    tar = tmp_path / "data.tar.gz"
+    tar.write_bytes(b"the archive")
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    run(str(empty), str(tar))                       # the archive is the only stream: files: []
+    only_debian = tmp_path / "onlydeb"
+    (only_debian / "DEBIAN").mkdir(parents=True)
+    (only_debian / "DEBIAN" / "control").write_text("x")
+    run(str(only_debian), str(tar))                 # everything skipped by the /DEBIAN prefix rule
+    shapes = tmp_path / "shapes"
+    (shapes / "a" / "b").mkdir(parents=True)
+    os.symlink("nowhere", str(shapes / "a" / "dangling"))
+    (shapes / "a" / "zero").write_bytes(b"")
+    (shapes / "a-b").write_bytes(b"x")              # Walk order: a, a/..., a-b -- not a global sort of the paths
+    (shapes / "DEBIANfoo").write_bytes(b"skipped")  # string prefix, not path component (build.go:229)
+    run(str(shapes), str(tar))

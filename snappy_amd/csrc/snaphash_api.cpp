@@ -1,13 +1,15 @@
 // snaphash_api.cpp -- the C ABI of libsnaphash.so (include/snaphash.h): context,
-// HBM/pinned staging, the chunked double-buffered streaming engine that feeds
-// the multi-buffer SHA-512 kernels, and the writeHashes / Verify passes built
-// on it.
+// HBM/pinned staging, the staging engine (batches in sub-slots, fill pool, copy stream)
+// that feeds the multi-buffer SHA-512 kernels, the plan of a call (planner.h), the in-library
+// and per-process multi-GPU forms, and the writeHashes / Verify passes built on them.
 //
 // Reference behaviour mirrored here (paths relative to the upstream tree):
 //   helpers/helpers.go:187-201  Sha512sum: whole-file digest, any read error fails
 //   snappy/build.go:216-270     writeHashes: archive digest first, then the walk;
 //                               the first error aborts, nothing is written
-// Hashing happens on the GPU only; there is no host fallback in this file.
+// There is no fallback in this file: without a gfx950 device nothing runs, and no error re-routes a call.  Which streams
+// of a call the kernels take and which the library's own host SHA-512 (hostsha.cpp) is planned before anything runs
+// (hash_sources_top) and reported afterwards (snaphash_stats_ex); SNAPHASH_FLAG_GPU_ONLY plans nothing.
 #include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>

@@ -39,7 +39,7 @@ FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER, FLAG_GPU_ONLY, FLAG_NO_NUMA 
 
 class Config(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("staging_bytes", ctypes.c_uint64),
-                ("kernel", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("stream", ctypes.c_void_p),
+                ("kernel", ctypes.c_uint32), ("deflate_depth", ctypes.c_uint32), ("stream", ctypes.c_void_p),
                 # ABI 2
                 ("devices", ctypes.POINTER(ctypes.c_int32)), ("n_devices", ctypes.c_uint32),
                 ("host_threads", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("reserved2", ctypes.c_uint32)]
@@ -226,10 +226,10 @@ class Context:
     # FLAG_GPU_ONLY (tests/conftest.py) so that every test exercises the HIP kernels unless it asks for the default.
     DEFAULT_FLAGS = 0
 
-    def __init__(self, device=-1, staging_bytes=0, kernel=KERNEL_AUTO, stream=None, devices=None, host_threads=0, flags=None):
+    def __init__(self, device=-1, staging_bytes=0, kernel=KERNEL_AUTO, stream=None, devices=None, host_threads=0, flags=None, deflate_depth=0):
         if flags is None:
             flags = Context.DEFAULT_FLAGS
-        cfg = Config(ctypes.sizeof(Config), device, staging_bytes, kernel, 0, stream)
+        cfg = Config(ctypes.sizeof(Config), device, staging_bytes, kernel, deflate_depth, stream)
         if devices is not None:
             self._devs = (ctypes.c_int32 * len(devices))(*devices)
             cfg.devices = ctypes.cast(self._devs, ctypes.POINTER(ctypes.c_int32))

@@ -29,10 +29,11 @@ static int die(snaphash_ctx *c, int rc, const char *what)
 
 static int usage(void)
 {
-    fprintf(stderr, "usage: snaphash [-d DEV,...] [-t HOST_THREADS] [-g] [-s] hash FILE... | tree DIR TAR | write DIR TAR |\n"
+    fprintf(stderr, "usage: snaphash [-d DEV,...] [-t HOST_THREADS] [-g] [-z DEPTH] [-s] hash FILE... | tree DIR TAR | write DIR TAR |\n"
                     "       verify DIR YAML [TAR] | build DIR OUT.tar.gz | gzip IN OUT.gz | cmp A B [A B ...] |\n"
                     "       dirupdated DIR_A DIR_B [PREFIX]\n"
-                    "       -g: every byte through the HIP kernels (SNAPHASH_FLAG_GPU_ONLY); default: every call is planned\n");
+                    "       -g: every byte through the HIP kernels (SNAPHASH_FLAG_GPU_ONLY); default: every call is planned\n"
+                    "       -z DEPTH: effort of `build` / `gzip` (hash-chain links per position; default 32, 64 = gzip -9's class)\n");
     return 2;
 }
 
@@ -62,6 +63,7 @@ int main(int argc, char **argv)
     for (; a < argc && argv[a][0] == '-' && argv[a][1]; a++) {
         if (!strcmp(argv[a], "-s")) show_stats = 1;
         else if (!strcmp(argv[a], "-g")) cfg.flags |= SNAPHASH_FLAG_GPU_ONLY;
+        else if (!strcmp(argv[a], "-z") && a + 1 < argc) cfg.deflate_depth = (uint32_t)strtoul(argv[++a], NULL, 10);
         else if (!strcmp(argv[a], "-t") && a + 1 < argc) cfg.host_threads = (uint32_t)strtoul(argv[++a], NULL, 10);
         else if (!strcmp(argv[a], "-d") && a + 1 < argc) {
             char *p = argv[++a];
@@ -78,7 +80,7 @@ int main(int argc, char **argv)
     if (argc < 3) return usage();
     snaphash_ctx *c = NULL;
     /* no engine option given: NULL config, so that SNAPHASH_DEVICES / SNAPHASH_HOST_THREADS apply (snaphash.h) */
-    int rc = snaphash_init((cfg.n_devices || cfg.host_threads || cfg.flags) ? &cfg : NULL, &c);
+    int rc = snaphash_init((cfg.n_devices || cfg.host_threads || cfg.flags || cfg.deflate_depth) ? &cfg : NULL, &c);
     if (rc) return die(NULL, rc, "snaphash_init");
     int ret = 0;
     if (!strcmp(argv[1], "hash")) {

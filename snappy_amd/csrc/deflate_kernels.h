@@ -18,7 +18,7 @@ static_assert(kDeflateSlot % 64 == 0, "slots are copied out in whole dwords");
 // launches (the bytes of the first launches travel on while the later ones run) and comes out as if in one.
 hipError_t launch_deflate_chunks(const uint8_t* d_in, uint64_t n_in, uint8_t* d_slots, uint32_t* d_sizes, uint32_t* d_toks,
                                  uint32_t chunk0, uint32_t count, uint32_t nchunks, uint32_t n_xcd /* L2 domains the grid goes round: hipDeviceAttributeNumberOfXccs */,
-                                 hipStream_t s);
+                                 uint32_t depth /* links walked per position: 0 = kDfDepth */, hipStream_t s);
 hipError_t launch_deflate_compact(const uint8_t* d_slots, const uint32_t* d_sizes, const uint64_t* d_prefix, uint8_t* d_out,
                                   uint32_t chunk0, uint32_t count, hipStream_t s);
 

@@ -295,7 +295,7 @@ __device__ __forceinline__ uint32_t extend_match(const ChunkLds& L, uint32_t p, 
 #endif
 
 // ---- searcher: the best match of one position ------------------------------------------------------------------
-__device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uint8_t* __restrict__ in, uint64_t n_in, uint64_t p64, uint64_t c1)
+__device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uint8_t* __restrict__ in, uint64_t n_in, uint64_t p64, uint64_t c1, uint32_t depth)
 {
     if (p64 >= c1) return 0u;
     const uint32_t p = (uint32_t)p64;
@@ -306,7 +306,7 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     // check words (the four bytes ending at the best length the batch started with -- a candidate that differs there
     // cannot be longer) travel together, then the survivors are extended.  Exactly the serial walk's result: the
     // check only ever spares work.
-    uint32_t best = kDfMinMatch - 1u, bdist = 0u, left = kDfDepth;
+    uint32_t best = kDfMinMatch - 1u, bdist = 0u, left = depth;
     uint32_t cur = p;
     bool more = true;
     while (more && left) {
@@ -338,7 +338,7 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
                     best = l;                                                                                   \
                     bdist = p - cand;                                                                           \
                     if (l >= kDfNice || l >= maxl) left = 0u;                                                   \
-                    else if (l >= kDfGood && left > kDfDepth / 4u) left = kDfDepth / 4u;                        \
+                    else if (l >= kDfGood && left > depth / 4u) left = depth / 4u;                              \
                 }                                                                                               \
             }                                                                                                   \
         }
@@ -360,7 +360,7 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
 // cache line of check words, neighbouring LDS banks), and a wave of unrelated positions gives that up for its fuller lanes.
 #if defined(SNAPHASH_DF_STREAM_SEARCH)
 __device__ __forceinline__ void search_segment_stream(ChunkLds& L, const uint8_t* __restrict__ in, uint64_t n_in, uint64_t seg64, uint64_t c1,
-                                                      uint32_t* __restrict__ res, uint32_t lane)
+                                                      uint32_t* __restrict__ res, uint32_t lane, uint32_t depth)
 {
     uint32_t pool = 0, pool_end = 0; // the wave's pool: positions [pool, pool_end) of the segment (uniform)
     bool tiles_left = true;
@@ -396,7 +396,7 @@ __device__ __forceinline__ void search_segment_stream(ChunkLds& L, const uint8_t
                     if (maxl < kDfMinMatch || p64 + 3u > n_in) {
                         res[rel] = res_pack(0u, 0u, byte);
                     } else {
-                        best = kDfMinMatch - 1u; bdist = 0u; left = kDfDepth; cur = p; more = true;
+                        best = kDfMinMatch - 1u; bdist = 0u; left = depth; cur = p; more = true;
                         active = true;
                     }
                 }
@@ -431,7 +431,7 @@ __device__ __forceinline__ void search_segment_stream(ChunkLds& L, const uint8_t
                         best = l;                                                                                   \
                         bdist = p - cand;                                                                           \
                         if (l >= kDfNice || l >= maxl) left = 0u;                                                   \
-                        else if (l >= kDfGood && left > kDfDepth / 4u) left = kDfDepth / 4u;                        \
+                        else if (l >= kDfGood && left > depth / 4u) left = depth / 4u;                              \
                     }                                                                                               \
                 }                                                                                                   \
             }
@@ -817,7 +817,7 @@ __device__ __forceinline__ void token_bits(const ChunkLds& L, bool dynamic, bool
 // sizes[c]: bytes chunk c produced; toks: nchunks * kDeflateTokWords words of scratch (the chunk's match tokens).
 __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __restrict__ in, uint64_t n_in, uint8_t* __restrict__ slots,
                                                               uint32_t* __restrict__ sizes, uint32_t* __restrict__ toks, uint32_t chunk0,
-                                                              uint32_t nchunks, uint32_t nx)
+                                                              uint32_t nchunks, uint32_t nx, uint32_t depth)
 {
     __shared__ ChunkLds L;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -938,10 +938,10 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
                 item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
                 if (item >= kSegTiles) break;
                 STAMP(t_wait, while (__hip_atomic_load(&L.across_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= item) __builtin_amdgcn_s_sleep(1));
-                STAMP(t_sea, L.res[j % 3u][item * 64u + lane] = search_position(L, in, n_in, c0 + (uint64_t)j * kDfSeg + item * 64u + lane, c1));
+                STAMP(t_sea, L.res[j % 3u][item * 64u + lane] = search_position(L, in, n_in, c0 + (uint64_t)j * kDfSeg + item * 64u + lane, c1, depth));
             }
 #else
-            STAMP(t_sea, search_segment_stream(L, in, n_in, c0 + (uint64_t)j * kDfSeg, c1, L.res[j % 3u], lane));
+            STAMP(t_sea, search_segment_stream(L, in, n_in, c0 + (uint64_t)j * kDfSeg, c1, L.res[j % 3u], lane, depth));
 #endif
         }
         SYNC_STAMPED(3);
@@ -1137,11 +1137,12 @@ __global__ __launch_bounds__(256) void deflate_compact_kernel(const uint8_t* __r
 }
 
 hipError_t launch_deflate_chunks(const uint8_t* d_in, uint64_t n_in, uint8_t* d_slots, uint32_t* d_sizes, uint32_t* d_toks,
-                                 uint32_t chunk0, uint32_t count, uint32_t nchunks, uint32_t n_xcd, hipStream_t s)
+                                 uint32_t chunk0, uint32_t count, uint32_t nchunks, uint32_t n_xcd, uint32_t depth, hipStream_t s)
 {
     if (count == 0) return hipSuccess;
     if (n_xcd == 0 || n_xcd > 64) n_xcd = 8;
-    hipLaunchKernelGGL(deflate_chunks_kernel, dim3(count), dim3(1024), 0, s, d_in, n_in, d_slots, d_sizes, d_toks, chunk0, nchunks, n_xcd);
+    if (depth == 0) depth = kDfDepth;
+    hipLaunchKernelGGL(deflate_chunks_kernel, dim3(count), dim3(1024), 0, s, d_in, n_in, d_slots, d_sizes, d_toks, chunk0, nchunks, n_xcd, depth);
     return hipGetLastError();
 }
 

@@ -101,6 +101,7 @@ struct DevCtx {
     hipStream_t copy_stream = nullptr; // H2D of batch k+1 overlaps the kernel of batch k
     uint64_t staging = kDefaultStaging;
     uint32_t kernel_pref = SNAPHASH_KERNEL_AUTO;
+    uint32_t deflate_depth = 0; // hash-chain links the DEFLATE search walks per position (snaphash_config.deflate_depth; 0 = kDfDepth)
     uint32_t n_xcd = 8; // XCDs (L2 domains) the device presents: 8 in SPX mode; the DEFLATE launch keeps a run of chunks on one
 
     std::vector<SubSlot> sub; // the hashing engine's batches in flight (pieces of slot[0..2])
@@ -1239,6 +1240,7 @@ try {
             if (v1) {
                 if (cfg->staging_bytes) c->staging = (cfg->staging_bytes + kAlign - 1) & ~(uint64_t)(kAlign - 1);
                 c->kernel_pref = cfg->kernel;
+                if (cfg->deflate_depth) c->deflate_depth = std::min<uint32_t>(std::max<uint32_t>(cfg->deflate_depth, 4u), 256u) & ~3u; // whole batches of four links
                 if (c->kernel_pref == SNAPHASH_KERNEL_QUAD && !have_quad_kernel()) {
                     rc = SNAPHASH_EINVAL;
                     e = hipSuccess;

@@ -36,12 +36,16 @@ typedef dfmodel::Tok Tok; // len == 0: literal
 // piece[0, n_piece): the staging piece the kernel is launched on; [c0, c1) the chunk inside it.  The parse is
 // tests/deflate_model.h (the serial restatement of the kernel's pipeline); the code construction and the block
 // framing below run the kernel's own routines (deflate_core.h).
+static uint32_t g_model_depth = 0; // 0 = kDfDepth; f3_model_gzip3 sets it (the product: snaphash_config.deflate_depth)
+
 void deflate_chunk(const uint8_t* piece, size_t n_piece, size_t c0, size_t c1, std::vector<uint8_t>& out)
 {
     const uint8_t* src = piece + c0;
     const uint32_t len = (uint32_t)(c1 - c0);
     std::vector<Tok> toks;
-    dfmodel::parse_chunk(piece, n_piece, c0, c1, dfmodel::Params(), toks);
+    dfmodel::Params P;
+    if (g_model_depth) P.depth = g_model_depth;
+    dfmodel::parse_chunk(piece, n_piece, c0, c1, P, toks);
     // symbol counts and the cost of both block kinds
     uint32_t llf[kNumLL] = {0}, df[kNumD] = {0};
     uint64_t extra_bits = 0, fixed_bits = 3 + 7;
@@ -133,6 +137,14 @@ uint8_t* f3_model_gzip2(const uint8_t* in, size_t n, size_t piece, size_t* out_l
     return p;
 }
 uint8_t* f3_model_gzip(const uint8_t* in, size_t n, size_t* out_len) { return f3_model_gzip2(in, n, 0, out_len); }
+// the same at another search depth (links walked per position; not thread-safe: a test harness)
+uint8_t* f3_model_gzip3(const uint8_t* in, size_t n, size_t piece, uint32_t depth, size_t* out_len)
+{
+    g_model_depth = depth;
+    uint8_t* p = f3_model_gzip2(in, n, piece, out_len);
+    g_model_depth = 0;
+    return p;
+}
 
 uint32_t f3_crc32(uint32_t crc, const uint8_t* p, size_t n) { return crc32_update(crc, p, n); }
 uint32_t f3_crc32_combine(uint32_t a, uint32_t b, uint64_t len2) { return crc32_combine(a, b, len2); }

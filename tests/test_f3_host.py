@@ -27,6 +27,8 @@ def f3(tmp_path_factory):
     L.f3_model_gzip.restype = ctypes.c_void_p
     L.f3_model_gzip2.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.f3_model_gzip2.restype = ctypes.c_void_p
+    L.f3_model_gzip3.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t)]
+    L.f3_model_gzip3.restype = ctypes.c_void_p
     L.f3_crc32.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
     L.f3_crc32.restype = ctypes.c_uint32
     L.f3_crc32_combine.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import trees
+from conftest import ROOT
 from test_f3_host import sample_inputs, _make_tree, f3  # noqa: F401  (the CPU model of the kernel's format)
 
 pytestmark = pytest.mark.gpu
@@ -40,6 +41,32 @@ def test_gpu_deflate_round_trips_and_equals_its_cpu_model(built_lib, f3):  # noq
             assert st["tar_bytes"] == len(data) and st["gz_bytes"] == len(gz)
             pieces = [min(1 << 20, len(data) - o) for o in range(0, len(data), 1 << 20)]
             assert st["chunks"] == sum((p + 65535) // 65536 for p in pieces)
+
+
+def test_deflate_depth_is_the_models_depth(built_lib, f3):  # noqa: F811
+    """snaphash_config.deflate_depth (ABI 4): the producer's effort -- hash-chain links walked per position.  At 8, 64 and
+    128 the GPU's bytes equal the serial model's at that depth, gzip reads them back, and a deeper walk never writes more
+    on compressible input (64 is the class of the reference's gzip level 9, clickdeb/deb.go:271)."""
+    import ctypes
+    from snappy_amd import Context
+    rng = np.random.default_rng(12)
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(2000)]
+    text = b" ".join(words[int(i)] for i in rng.zipf(1.3, size=400000) % 2000)[:1600000]
+    src = b"".join(open(os.path.join(ROOT, "snappy_amd", "csrc", f), "rb").read() for f in ("hostpass.cpp", "walk.cpp", "planner.cpp"))
+    sizes = {}
+    for depth in (8, 0, 64, 128):
+        with Context(staging_bytes=1 << 20, deflate_depth=depth) as c:
+            for name, data in (("text", text), ("sources", src)):
+                gz = c.gzip_buffer(data)
+                assert gzip.decompress(gz) == data, (name, depth)
+                n = ctypes.c_size_t()
+                p = f3.f3_model_gzip3(data, len(data), 1 << 20, depth, ctypes.byref(n))
+                model = ctypes.string_at(p, n.value)
+                f3.f3_free(p)
+                assert gz == model, (name, depth)
+                sizes[(name, depth or 32)] = len(gz)
+    for name in ("text", "sources"):
+        assert sizes[(name, 8)] > sizes[(name, 32)] > sizes[(name, 64)] >= sizes[(name, 128)], sizes
 
 
 def test_tar_create_matches_tarfile_view_of_the_tree(built_lib, tmp_path):

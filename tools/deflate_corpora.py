@@ -57,8 +57,13 @@ def fill(unit):
     return b"".join(parts)[:SIZE]
 
 
-with Context() as c:
-    for name, data in (("Zipf-word text", text()), ("this repo's sources (tar)", fill(sources())), ("binaries (.so + python)", fill(binaries()))):
+depths = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
+corpora = (("Zipf-word text", text()), ("this repo's sources (tar)", fill(sources())), ("binaries (.so + python)", fill(binaries())))
+for depth in depths:
+  if len(depths) > 1:
+      print("## deflate_depth = %d" % (depth or 32), flush=True)
+  with Context(deflate_depth=depth) as c:
+    for name, data in corpora:
         c.gzip_buffer(data[:1 << 20])
         best = None
         for _ in range(3):

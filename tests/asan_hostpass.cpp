@@ -6,10 +6,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
 #include "../snappy_amd/csrc/hostpass.h"
+#include "../snappy_amd/csrc/planner.h"
 
 using namespace snaphash;
 
@@ -99,6 +101,41 @@ int main(int argc, char** argv)
     std::vector<int32_t> shard(1000);
     for (auto& l : lens) l = rnd() % (1u << 26);
     if (lpt_assign(lens.data(), lens.size(), 8, shard.data()) != SNAPHASH_OK) return 11;
-    printf("asan driver ok: %zu records, %d mutated documents accepted, %d rejected; %d random names emitted and read back, %d refused\n", recs.size(), ok, bad, emitted, refused);
+    // The planner (planner.cpp) on random stream lists and models, degenerate ones included: every stream is planned exactly
+    // once, the sums add up, a plan never asks for more threads than the model allows or than it has streams for.
+    int plans = 0;
+    for (int it = 0; it < 3000; ++it) {
+        const size_t n = (it % 50 == 0) ? 0 : 1 + rnd() % ((it % 9 == 0) ? 40000 : 300);
+        std::vector<uint64_t> pl(n);
+        for (auto& l : pl) {
+            switch (rnd() % 6) {
+            case 0: l = 0; break;
+            case 1: l = rnd() % 300; break;
+            case 2: l = (uint64_t)rnd() << (rnd() % 8); break; // up to 2^39
+            case 3: l = 1u << 20; break;
+            default: l = rnd() % (1u << 22); break;
+            }
+        }
+        PlanModel pm;
+        pm.n_devices = 1 + rnd() % 8;
+        pm.cpus = (it % 11 == 0) ? 1 : 1 + rnd() % 300;
+        pm.fill_threads = rnd() % 14;
+        pm.host_threads = (rnd() % 3 == 0) ? 1 + rnd() % 300 : 0;
+        pm.from_files = rnd() & 1;
+        if (rnd() % 4 == 0) pm.host_rate = 1e6 * (1 + rnd() % 5000);
+        if (rnd() % 4 == 0) pm.gpu_link = 1e8 * (1 + rnd() % 1000);
+        if (rnd() % 4 == 0) pm.gpu_latency = 1e-6 * (rnd() % 100000);
+        const PlanResult r = plan_streams(pl.data(), n, pm);
+        if (r.on_host.size() != n) return 14;
+        uint64_t hb = 0, hs = 0;
+        for (size_t i = 0; i < n; ++i) { if (r.on_host[i] > 1) return 15; if (r.on_host[i]) { hb += pl[i]; ++hs; } }
+        if (hb != r.host_bytes || hs != r.host_streams) return 16;
+        if ((hs == 0) != (r.host_threads == 0)) return 17;
+        if (r.host_threads > hs || r.host_threads > std::max(pm.host_threads, pm.cpus)) return 18;
+        if (!(r.gpu_seconds >= 0) || !(r.host_seconds >= 0)) return 19;
+        if (hs == n && n && r.gpu_seconds != 0) return 20;
+        ++plans;
+    }
+    printf("asan driver ok: %d plans, %zu records, %d mutated documents accepted, %d rejected; %d random names emitted and read back, %d refused\n", plans, recs.size(), ok, bad, emitted, refused);
     return 0;
 }

@@ -258,7 +258,8 @@ def test_hostpass_under_asan_and_ubsan(tmp_path):
                            os.path.join(ROOT, "snappy_amd", "csrc", "hostpass.cpp"),
                            os.path.join(ROOT, "snappy_amd", "csrc", "yamlscalar.cpp"),
                            os.path.join(ROOT, "snappy_amd", "csrc", "walk.cpp"),
-                           os.path.join(ROOT, "snappy_amd", "csrc", "hostfill.cpp"), "-pthread"])
+                           os.path.join(ROOT, "snappy_amd", "csrc", "hostfill.cpp"),
+                           os.path.join(ROOT, "snappy_amd", "csrc", "planner.cpp"), "-pthread"])
     build, tar = trees.make_synthetic_tree(str(tmp_path / "t"), [5, 0, 300, 70000, 12, 1, 2, 3])
     r = subprocess.run([exe, build, os.path.join(GOLDEN, "hashes_simple.yaml")], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300)

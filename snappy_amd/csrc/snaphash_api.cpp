@@ -585,7 +585,13 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         for (uint32_t id : active) total_rem += (long double)(src[id].gpu_len - done[id]);
         uint64_t S = S_full;
         if (job_bytes + kAlign * n > S_full) {
-            if (batch < 3) S = std::max<uint64_t>((S_full >> (3 - batch)) & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20));
+            if (batch < 3) {
+                // ... but never so small that only some streams get their floor: a batch costs the kernel chain its LARGEST
+                // share's time, so 256 streams at 32 KiB cost what all 1 250 at 32 KiB would (the file-source shard's first
+                // three batches: 0.75 ms of kernel each for 8, 16 and 32 MiB; profiles/r04_shard_trace.txt)
+                const uint64_t every = std::min<uint64_t>(S_full, (seg_floor + kAlign) * (uint64_t)active.size());
+                S = std::max<uint64_t>({(S_full >> (3 - batch)) & ~(uint64_t)(kAlign - 1), every & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20)});
+            }
             if (total_rem < 2 * (long double)S) { // the end: half of what is left, while every stream can still get its floor
                 const uint64_t half = ((uint64_t)(total_rem / 2) + kAlign * active.size()) & ~(uint64_t)(kAlign - 1);
                 const uint64_t least = std::max<uint64_t>(S_full >> 5, (seg_floor + kAlign) * active.size());

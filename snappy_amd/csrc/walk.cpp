@@ -55,49 +55,16 @@ void list_dir(DirList& dl)
         }
 }
 
-// Pre-order assembly of the listings: appends dirs[di]'s children (recursively); dirs[di] itself is ents[self].  Returns
-// the index of the entry at which the serial walk would have failed (errno in *err_no), or -1.
-int64_t assemble(const std::vector<DirList>& dirs, size_t di, std::vector<WalkEntry>& ents, size_t self, int* err_no)
-{
-    const DirList& dl = dirs[di];
-    if (dl.open_failed) {
-        // filepath.Walk: `names, err := readDirNames(path); if err != nil { return walkFn(path, info, err) }` -- the
-        // callback runs a SECOND time for the directory, and neither of the reference's callbacks looks at the err
-        // it is handed (snappy/build.go:228 ignores it, clickdeb/deb.go:285-286 shadows it with its own Lstat): the
-        // entry is emitted again and the walk goes on behind it.
-        WalkEntry again;
-        again.path = dl.path;
-        again.st = ents[self].st;
-        again.have_st = ents[self].have_st;
-        ents.push_back(std::move(again));
-        return -1;
-    }
-    for (const Child& c : dl.kids) {
-        WalkEntry e;
-        e.path = dl.path + "/" + c.name;
-        if (c.lstat_errno) { *err_no = c.lstat_errno; ents.push_back(std::move(e)); return (int64_t)ents.size() - 1; }
-        if (c.have_st) { e.st = c.st; e.have_st = true; }
-        const size_t me = ents.size();
-        ents.push_back(std::move(e));
-        if (c.dir >= 0) {
-            const int64_t bad = assemble(dirs, (size_t)c.dir, ents, me, err_no);
-            if (bad >= 0) return bad;
-        }
-    }
-    return -1;
-}
-
 unsigned walk_threads(size_t items, size_t per_thread)
 {
     return (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, usable_cpus()), items / per_thread));
 }
 
 // Lists the tree under root level by level: the directories of one level are independent, so they are listed on a few
-// threads (a 10 000-file tree in 100 directories: ~6 ms of readdir + sort on one thread); then the listings are put
-// together in Walk's pre-order.
-int64_t walk_names(const std::string& root, std::vector<WalkEntry>& ents, int* err_no)
+// threads (a 10 000-file tree in 100 directories: ~6 ms of readdir + sort on one thread).
+void list_tree(const std::string& root, std::vector<DirList>& dirs)
 {
-    std::vector<DirList> dirs(1);
+    dirs.assign(1, DirList());
     dirs[0].path = root;
     size_t lo = 0;
     while (lo < dirs.size()) {
@@ -127,7 +94,6 @@ int64_t walk_names(const std::string& root, std::vector<WalkEntry>& ents, int* e
                 }
         lo = hi;
     }
-    return assemble(dirs, 0, ents, 0, err_no);
 }
 
 } // namespace
@@ -147,23 +113,76 @@ int walk_entries(const char* root_c, std::vector<WalkEntry>& ents, int* err_no, 
         return -1;
     }
     ents[0].have_st = true;
-    int dir_errno = 0;
-    int64_t dir_bad = -1; // entry whose children could not be listed, or whose look-ahead Lstat failed
+    if (!S_ISDIR(ents[0].st.st_mode)) return 0;
     const bool trace = getenv("SNAPHASH_TRACE_TREE") != nullptr;
-    const auto t_list0 = std::chrono::steady_clock::now();
-    if (S_ISDIR(ents[0].st.st_mode)) dir_bad = walk_names(root, ents, &dir_errno);
-    const auto t_list1 = std::chrono::steady_clock::now();
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<DirList> dirs;
+    list_tree(root, dirs);
+    const auto t1 = std::chrono::steady_clock::now();
 
-    const size_t n = ents.size();
+    // Where every entry goes in Walk's pre-order: a directory's entries follow it at once, each child followed by its own
+    // subtree.  A directory that cannot be listed is followed by ONE entry: itself again --
+    // filepath.Walk: `names, err := readDirNames(path); if err != nil { return walkFn(path, info, err) }`: the callback
+    // runs a SECOND time for the directory, and neither of the reference's callbacks looks at the err it is handed
+    // (snappy/build.go:228 ignores it, clickdeb/deb.go:285-286 shadows it with its own Lstat): the entry is emitted
+    // again and the walk goes on behind it.
+    const size_t nd = dirs.size();
+    std::vector<size_t> count(nd, 0), start(nd, 0); // entries below a directory; index of the first of them
+    for (size_t d = nd; d-- > 0;) { // children were listed after their parents: their counts are final here
+        if (dirs[d].open_failed) { count[d] = 1; continue; }
+        size_t c = 0;
+        for (const Child& k : dirs[d].kids) c += 1 + (k.dir >= 0 ? count[(size_t)k.dir] : 0);
+        count[d] = c;
+    }
+    start[0] = 1;
+    struct Task { uint32_t dir, k0, k1; size_t first; };
+    std::vector<Task> tasks;
+    for (size_t d = 0; d < nd; ++d) { // parents before children: start[d] is known when d is reached
+        if (dirs[d].open_failed) { tasks.push_back(Task{(uint32_t)d, 0, 0, start[d]}); continue; }
+        size_t at = start[d];
+        const std::vector<Child>& kids = dirs[d].kids;
+        for (size_t k = 0; k < kids.size(); ++k) {
+            if (k % 256 == 0) tasks.push_back(Task{(uint32_t)d, (uint32_t)k, (uint32_t)std::min(kids.size(), k + 256), at});
+            if (kids[k].dir >= 0) { start[(size_t)kids[k].dir] = at + 1; at += 1 + count[(size_t)kids[k].dir]; }
+            else at += 1;
+        }
+    }
+    const size_t n = 1 + count[0];
+    ents.resize(n);
+
+    // Every entry's path and Lstat, a few hundred entries a task, on a few threads.
     const unsigned T = walk_threads(n, 512);
     std::vector<int64_t> bad(T, -1);
     std::vector<int> bad_errno(T, 0);
+    std::atomic<size_t> next{0};
     auto work = [&](unsigned t) {
-        const size_t lo = n * t / T, hi = n * (t + 1) / T;
-        for (size_t i = lo; i < hi; ++i) {
-            if (ents[i].have_st) continue;
-            if (lstat(ents[i].path.c_str(), &ents[i].st) != 0) { bad[t] = (int64_t)i; bad_errno[t] = errno; return; }
-            ents[i].have_st = true;
+        auto fail = [&](size_t idx, int e) { if (bad[t] < 0 || (int64_t)idx < bad[t]) { bad[t] = (int64_t)idx; bad_errno[t] = e; } };
+        for (;;) {
+            const size_t ti = next.fetch_add(1);
+            if (ti >= tasks.size()) return;
+            const Task& tk = tasks[ti];
+            const DirList& dl = dirs[tk.dir];
+            if (dl.open_failed) { // the directory again
+                WalkEntry& e = ents[tk.first];
+                e.path = dl.path;
+                if (lstat(e.path.c_str(), &e.st) != 0) fail(tk.first, errno);
+                else e.have_st = true;
+                continue;
+            }
+            size_t at = tk.first;
+            for (uint32_t k = tk.k0; k < tk.k1; ++k) {
+                const Child& c = dl.kids[k];
+                WalkEntry& e = ents[at];
+                e.path.reserve(dl.path.size() + 1 + c.name.size());
+                e.path = dl.path;
+                e.path += '/';
+                e.path += c.name;
+                if (c.lstat_errno) fail(at, c.lstat_errno); // (the look-ahead of a file system that gives no types)
+                else if (c.have_st) { e.st = c.st; e.have_st = true; }
+                else if (lstat(e.path.c_str(), &e.st) != 0) fail(at, errno);
+                else e.have_st = true;
+                at += 1 + (c.dir >= 0 ? count[(size_t)c.dir] : 0);
+            }
         }
     };
     {
@@ -174,24 +193,18 @@ int walk_entries(const char* root_c, std::vector<WalkEntry>& ents, int* err_no, 
     }
     if (trace) {
         const auto t2 = std::chrono::steady_clock::now();
-        fprintf(stderr, "snaphash walk: names (list + sort + pre-order) %.2f ms, Lstat of %zu entries on %u threads %.2f ms\n",
-                std::chrono::duration<double, std::milli>(t_list1 - t_list0).count(), n, T, std::chrono::duration<double, std::milli>(t2 - t_list1).count());
+        fprintf(stderr, "snaphash walk: listing %zu directories (readdir + sort) %.2f ms, paths + Lstat of %zu entries on %u threads %.2f ms\n", nd,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), n, T, std::chrono::duration<double, std::milli>(t2 - t1).count());
     }
     int64_t first_bad = -1;
     int first_errno = 0;
     for (unsigned t = 0; t < T; ++t)
         if (bad[t] >= 0 && (first_bad < 0 || bad[t] < first_bad)) { first_bad = bad[t]; first_errno = bad_errno[t]; }
-    // a directory that could not be listed fails AFTER its own Lstat and visit, before anything behind it
-    bool keep_bad = false;
-    if (dir_bad >= 0 && (first_bad < 0 || dir_bad < first_bad)) {
-        first_bad = dir_bad;
-        first_errno = dir_errno;
-        keep_bad = ents[(size_t)dir_bad].have_st;
-    }
     if (first_bad < 0) return 0;
+    // the serial walk stops at the first entry it cannot Lstat: everything in front of it was visited
     if (err_no) *err_no = first_errno;
     if (err_path) *err_path = ents[(size_t)first_bad].path;
-    ents.resize((size_t)first_bad + (keep_bad ? 1 : 0));
+    ents.resize((size_t)first_bad);
     return -1;
 }
 

@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <functional>
 #include <queue>
 #include <thread>
 
@@ -125,8 +126,9 @@ bool plain_safe_name(const std::string& s)
     static const char* const resolved[] = {"y", "Y", "yes", "Yes", "YES", "on", "On", "ON", "n", "N", "no", "No", "NO",
                                            "off", "Off", "OFF", "true", "True", "TRUE", "false", "False", "FALSE",
                                            "null", "Null", "NULL", nullptr};
-    for (int i = 0; resolved[i]; ++i)
-        if (s == resolved[i]) return false;
+    if (s.size() <= 5) // (the longest of them is "false")
+        for (int i = 0; resolved[i]; ++i)
+            if (s == resolved[i]) return false;
     return true;
 }
 
@@ -433,10 +435,21 @@ bool digest_matches_hex(const uint8_t d[64], const std::string& hex)
 int lpt_assign(const uint64_t* lens, size_t n, int nshards, int32_t* shard_of)
 {
     if (nshards <= 0 || (!lens && n) || (!shard_of && n)) return SNAPHASH_EINVAL;
+    // longest first, ties in list order (what a stable sort by block count gives): one sort of packed keys when the
+    // counts fit 32 bits (a stream under 512 GiB), the comparator form otherwise
+    auto blocks = [&](size_t i) { return (lens[i] + 17 + 127) / 128; };
     std::vector<uint32_t> order(n);
-    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
-    auto blocks = [&](uint32_t i) { return (lens[i] + 17 + 127) / 128; };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return blocks(a) > blocks(b); });
+    bool small = n <= 0xffffffffull;
+    for (size_t i = 0; i < n && small; ++i) small = blocks(i) <= 0xffffffffull;
+    if (small) {
+        std::vector<uint64_t> key(n);
+        for (size_t i = 0; i < n; ++i) key[i] = (blocks(i) << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+        std::sort(key.begin(), key.end(), std::greater<uint64_t>());
+        for (size_t i = 0; i < n; ++i) order[i] = 0xffffffffu - (uint32_t)key[i];
+    } else {
+        for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return blocks(a) > blocks(b); });
+    }
     typedef std::pair<uint64_t, int> Load; // (blocks so far, shard)
     std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
     for (int s = 0; s < nshards; ++s) heap.push(Load(0, s));

@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <string_view>
 #include <functional>
 #include <queue>
 #include <thread>
@@ -319,7 +320,7 @@ bool unhex64(const std::string& s, uint8_t out[64])
 int parse_yaml(const char* text, size_t len, ParsedHashes& out)
 {
     out = ParsedHashes();
-    std::vector<std::string> lines;
+    std::vector<std::string_view> lines; // views into the caller's text: a line is copied only when it is worked on
     {
         size_t i = 0;
         while (i < len) {
@@ -332,9 +333,10 @@ int parse_yaml(const char* text, size_t len, ParsedHashes& out)
     bool in_files = false;
     int skip_indent = -1; // inside a nested block we ignore (xattr)
     ParsedRecord* cur = nullptr;
-    auto indent_of = [](const std::string& l) { size_t k = 0; while (k < l.size() && l[k] == ' ') ++k; return k; };
+    auto indent_of = [](std::string_view l) { size_t k = 0; while (k < l.size() && l[k] == ' ') ++k; return k; };
+    std::string line;
     for (size_t li = 0; li < lines.size(); ++li) {
-        std::string line = lines[li];
+        line.assign(lines[li].data(), lines[li].size());
         while (!line.empty() && (line.back() == '\r')) line.pop_back();
         size_t ind = 0;
         while (ind < line.size() && line[ind] == ' ') ++ind;
@@ -346,13 +348,13 @@ int parse_yaml(const char* text, size_t len, ParsedHashes& out)
             const size_t colon = line.find(": ", ind);
             if (colon != std::string::npos && colon + 2 < line.size()) {
                 while (li + 1 < lines.size()) {
-                    std::string nx = lines[li + 1];
-                    while (!nx.empty() && (nx.back() == '\r' || nx.back() == ' ')) nx.pop_back();
+                    std::string_view nx = lines[li + 1];
+                    while (!nx.empty() && (nx.back() == '\r' || nx.back() == ' ')) nx.remove_suffix(1);
                     const size_t ni = indent_of(nx);
                     if (nx.empty() || ni <= key_col) break;
                     while (!line.empty() && line.back() == ' ') line.pop_back();
                     line += ' ';
-                    line.append(nx, ni, std::string::npos);
+                    line.append(nx.data() + ni, nx.size() - ni);
                     ++li;
                 }
             }

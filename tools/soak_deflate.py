@@ -23,6 +23,8 @@ subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so,
 f3 = ctypes.CDLL(so)
 f3.f3_model_gzip2.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
 f3.f3_model_gzip2.restype = ctypes.c_void_p
+f3.f3_model_gzip3.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t)]
+f3.f3_model_gzip3.restype = ctypes.c_void_p
 f3.f3_free.argtypes = [ctypes.c_void_p]
 rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
 
@@ -67,10 +69,11 @@ while time.time() < t_end:
     if replay >= 0 and it < replay:
         it += 1
         continue
-    c = ctxs.get(staging) or ctxs.setdefault(staging, Context(staging_bytes=staging))
+    depth = int(rng.choice([0, 0, 0, 4, 8, 48, 64, 128]))  # snaphash_config.deflate_depth (0 = the default, 32)
+    c = ctxs.get((staging, depth)) or ctxs.setdefault((staging, depth), Context(staging_bytes=staging, deflate_depth=depth))
     if replay >= 0:
         n = ctypes.c_size_t()
-        p = f3.f3_model_gzip2(data, len(data), staging, ctypes.byref(n))
+        p = f3.f3_model_gzip3(data, len(data), staging, depth, ctypes.byref(n))
         model = ctypes.string_at(p, n.value)
         f3.f3_free(p)
         outs = [c.gzip_buffer(data) for _ in range(300)]
@@ -84,12 +87,12 @@ while time.time() < t_end:
             print("  first differing byte %d of %d / %d; inflates: %s" % (first, len(g), len(model), zlib.decompressobj(-15).decompress(g[10:-8]) == data))
         break
     gz = c.gzip_buffer(data)
-    assert zlib.decompressobj(-15).decompress(gz[10:-8]) == data, ("inflate", it, target, staging)
+    assert zlib.decompressobj(-15).decompress(gz[10:-8]) == data, ("inflate", it, target, staging, depth)
     n = ctypes.c_size_t()
-    p = f3.f3_model_gzip2(data, len(data), staging, ctypes.byref(n))
+    p = f3.f3_model_gzip3(data, len(data), staging, depth, ctypes.byref(n))
     model = ctypes.string_at(p, n.value)
     f3.f3_free(p)
-    assert gz == model, ("model", it, target, staging)
+    assert gz == model, ("model", it, target, staging, depth)
     it += 1
     total += len(data)
     if time.time() >= t_note:  # (a run that says nothing for minutes is taken for hung)
@@ -97,4 +100,4 @@ while time.time() < t_end:
         t_note = time.time() + 60.0
 for c in ctxs.values():
     c.close()
-print("soak_deflate: %d inputs, %.1f MiB, all inflate to their input and equal the CPU model" % (it, total / 2**20))
+print("soak_deflate: %d inputs, %.1f MiB (search depths 4 / 8 / 32 / 48 / 64 / 128 at random), all inflate to their input and equal the CPU model" % (it, total / 2**20))

@@ -36,7 +36,8 @@
  *     xGMI.  No signal handlers are installed (the Go runtime owns them).
  *   - Process-wide effects: snaphash_init raises the soft RLIMIT_NOFILE to the hard limit (at most 65 536, as the Go
  *     runtime itself does at start-up) so that a hashing call can keep a file's descriptor open between the batches the
- *     file appears in; the calling thread's memory policy and CPU affinity are left as they were found.
+ *     file appears in (SNAPHASH_FLAG_KEEP_RLIMIT / SNAPHASH_KEEP_RLIMIT=1 leave it alone); the calling thread's memory
+ *     policy and CPU affinity are left as they were found.
  *   - Digests are raw 64-byte big-endian SHA-512 values; the Go wrapper
  *     hex-encodes them with encoding/hex (lowercase, helpers.go:200).
  */
@@ -85,7 +86,11 @@ enum { /* snaphash_config.flags */
     /* ---- ABI 3 ---- */
     SNAPHASH_FLAG_GPU_ONLY = 8,     /* every byte of every stream is hashed by the HIP kernels, whatever it costs (the
                                        roofline runs and the parity tests of the kernels); host_threads is ignored */
-    SNAPHASH_FLAG_NO_NUMA = 16      /* do not place staging memory and fill threads on the GPU's NUMA node */
+    SNAPHASH_FLAG_NO_NUMA = 16,     /* do not place staging memory and fill threads on the GPU's NUMA node */
+    /* ---- ABI 4 ---- */
+    SNAPHASH_FLAG_KEEP_RLIMIT = 32  /* leave RLIMIT_NOFILE as it is (an application that select()s on descriptors must stay
+                                       below FD_SETSIZE): files are then kept open between batches only within the soft
+                                       limit found, the rest are opened segment by segment.  Also: SNAPHASH_KEEP_RLIMIT=1 */
 };
 
 typedef struct snaphash_config {

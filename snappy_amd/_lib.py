@@ -34,7 +34,7 @@ EXPORTS = [
     "snaphash_shard_plan", "snaphash_shard_rows", "snaphash_shard_count", "snaphash_shard_streams", "snaphash_shard_bytes",
     "snaphash_shard_path", "snaphash_shard_hash", "snaphash_shard_emit", "snaphash_shard_free",
 ]
-FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER, FLAG_GPU_ONLY, FLAG_NO_NUMA = 1, 2, 4, 8, 16
+FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER, FLAG_GPU_ONLY, FLAG_NO_NUMA, FLAG_KEEP_RLIMIT = 1, 2, 4, 8, 16, 32
 
 
 class Config(ctypes.Structure):

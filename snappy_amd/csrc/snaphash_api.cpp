@@ -1214,7 +1214,8 @@ try {
         struct rlimit rl;
         if (getrlimit(RLIMIT_NOFILE, &rl) == 0) {
             const rlim_t want = rl.rlim_max == RLIM_INFINITY ? 65536 : std::min<rlim_t>(rl.rlim_max, 65536);
-            if (rl.rlim_cur != RLIM_INFINITY && rl.rlim_cur < want) {
+            const bool keep = (cfg && cfg->struct_size >= sizeof(snaphash_config) && (cfg->flags & SNAPHASH_FLAG_KEEP_RLIMIT)) || getenv("SNAPHASH_KEEP_RLIMIT");
+            if (!keep && rl.rlim_cur != RLIM_INFINITY && rl.rlim_cur < want) {
                 struct rlimit up = rl;
                 up.rlim_cur = want;
                 if (setrlimit(RLIMIT_NOFILE, &up) == 0) rl = up;

@@ -485,7 +485,8 @@ def test_descriptor_budget_smaller_than_the_tree(built_lib, oracle, tmp_path):
         "resource.setrlimit(resource.RLIMIT_NOFILE, (560, 560))\n"   # budget = 560 - 512 = 48 descriptors for 702 files
         "sys.path.insert(0, %r)\n"
         "from snappy_amd import Context, _lib\n"
-        "with Context(staging_bytes=4 << 20, flags=_lib.FLAG_GPU_ONLY) as c:\n"   # 4 MiB staging: every file of any size spans batches
+        "with Context(staging_bytes=4 << 20, flags=_lib.FLAG_GPU_ONLY | _lib.FLAG_KEEP_RLIMIT) as c:\n"   # 4 MiB staging: every file of any size spans batches
+        "    assert resource.getrlimit(resource.RLIMIT_NOFILE)[0] == 560\n"
         "    y = c.tree(%r, %r)\n"
         "    assert c.stats()['launches'] > 8\n"
         "sys.stdout.buffer.write(y)\n" % (ROOT, build, tar))

@@ -482,7 +482,7 @@ def test_descriptor_budget_smaller_than_the_tree(built_lib, oracle, tmp_path):
     want = oracle.hashes_yaml(build, tar)
     code = (
         "import resource, sys\n"
-        "resource.setrlimit(resource.RLIMIT_NOFILE, (560, 560))\n"   # budget = 560 - 512 = 48 descriptors for 702 files
+        "resource.setrlimit(resource.RLIMIT_NOFILE, (560, min(4096, resource.getrlimit(resource.RLIMIT_NOFILE)[1])))\n"   # budget = 560 - 512 = 48 descriptors for 702 files
         "sys.path.insert(0, %r)\n"
         "from snappy_amd import Context, _lib\n"
         "with Context(staging_bytes=4 << 20, flags=_lib.FLAG_GPU_ONLY | _lib.FLAG_KEEP_RLIMIT) as c:\n"   # 4 MiB staging: every file of any size spans batches

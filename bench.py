@@ -731,15 +731,16 @@ def main():
         # ---- (ii) end to end: the timed region ---------------------------------------------------------------------
         last = {}
 
-        def step():
+        def step(c=None, key="yaml"):
+            c = c or ectx
             if world == 1 and not force_dist:
-                last["yaml"] = ectx.tree(build, tar)
+                last[key] = c.tree(build, tar)
                 return
             with ShardedTree(build, tar, rank, world) as st:
-                mine = st.hash(ectx)
+                mine = st.hash(c)
                 slabs = st.gather(mine, device=coll_device)
                 if rank == 0:
-                    last["yaml"] = st.emit(slabs)
+                    last[key] = st.emit(slabs)
         for _ in range(args.warmup):
             step()
         fence()
@@ -807,6 +808,36 @@ def main():
             bctx.close()
             r["source_placement"] = numa_note
             end_to_end["buffers_sharded"] = r
+            if use_dist and args.legs == "full":  # (--legs full: an optional collective leg is not worth a rank's failure costing the line)
+                # The same sharded pass in the library's DEFAULT configuration: every rank plans its share (planner.h) and the
+                # host cores beside its staging fill take what shortens it -- what the whole node does when its cores may
+                # help.  Never `value`: the headline keeps every byte on the GPUs.
+                try:
+                    dctx = Context(device=device, kernel=kern, flags=0)
+                    best = None
+                    for _ in range(3):
+                        fence()
+                        t0 = time.perf_counter()
+                        step(dctx, "yaml_default")
+                        fence()
+                        dt = allmax(time.perf_counter() - t0)
+                        best = dt if best is None else min(best, dt)
+                    ex = dctx.stats_ex()
+                    dctx.close()
+                    per = gather_obj({"gpu_bytes": int(ex["gpu_bytes"]), "host_bytes": int(ex["host_bytes"]), "host_streams": int(ex["host_streams"])})
+                    if rank == 0:
+                        if last.get("yaml_default") != last["yaml"]:
+                            raise SystemExit("PARITY FAILURE: the default-configuration sharded pass writes another hashes.yaml")
+                        end_to_end["tree_sharded_default"] = {
+                            "what": "the timed pass with every rank in the DEFAULT configuration (planned; host cores take a share)",
+                            "ms": round(best * 1e3, 2), "GiBps": round(total_bytes / GiB / best, 2), "per_rank": per,
+                            "usable_cpus_per_rank": int(_lib.lib().snaphash_usable_cpus()),
+                            "parity": "hashes.yaml byte-identical to the GPU-only pass", "best_of": 3}
+                except SystemExit:
+                    raise
+                except Exception as e:  # noqa: BLE001
+                    if rank == 0:
+                        end_to_end["tree_sharded_default"] = {"error": repr(e)[:300]}
         if full_legs:
             verify_ms = None
             t0 = time.perf_counter()

@@ -589,7 +589,10 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
                 // ... but never so small that only some streams get their floor: a batch costs the kernel chain its LARGEST
                 // share's time, so 256 streams at 32 KiB cost what all 1 250 at 32 KiB would (the file-source shard's first
                 // three batches: 0.75 ms of kernel each for 8, 16 and 32 MiB; profiles/r04_shard_trace.txt)
-                const uint64_t every = std::min<uint64_t>(S_full, (seg_floor + kAlign) * (uint64_t)active.size());
+                // (That is a concern of jobs bound by their kernel chain: up to ~2 000 streams, whose 44 MB/s each do not
+                // outrun the link.  With more streams the link is the bound and the first copy should start early: the C2
+                // tree's first batch was a whole 256 MiB buffer, 4 ms of fill with the link idle.)
+                const uint64_t every = active.size() <= 2048 ? std::min<uint64_t>(S_full, (seg_floor + kAlign) * (uint64_t)active.size()) : 0;
                 S = std::max<uint64_t>({(S_full >> (3 - batch)) & ~(uint64_t)(kAlign - 1), every & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20)});
             }
             if (total_rem < 2 * (long double)S) { // the end: half of what is left, while every stream can still get its floor

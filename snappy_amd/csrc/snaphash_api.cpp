@@ -602,6 +602,12 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
             }
         }
         const uint64_t floor_q = std::max<uint64_t>(seg_floor, (S / kTargetStreams) & ~(uint64_t)(kAlign - 1));
+        // What the shares are taken of: the batch less the alignment every segment may cost.  Without that the shares of
+        // ALL streams came to a whole batch, the padding pushed the last dozen streams of the list out of every batch, and
+        // they were hashed at the end, alone, at 44 MB/s each (5 000 x 1 MiB: the last four kernels took 26 ms instead of
+        // 6, 114 ms for a job whose copies take 92; profiles/r04_shard_trace.txt).
+        const uint64_t pad = kAlign * (uint64_t)active.size();
+        const uint64_t S_share = pad < S / 2 ? S - pad : S;
         rc = ensure_jobs(c, &sl.h_jobs, &sl.d_jobs, &sl.jobs_cap, active.size());
         if (rc) return rc;
 
@@ -614,7 +620,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         for (uint32_t id : active) {
             if (full) { still.push_back(id); continue; }
             const uint64_t rem = src[id].gpu_len - done[id];
-            uint64_t quota = total_rem > (long double)S ? (uint64_t)((long double)rem * (long double)S / total_rem) : rem;
+            uint64_t quota = total_rem > (long double)S ? (uint64_t)((long double)rem * (long double)S_share / total_rem) : rem;
             quota = std::max(quota & ~(uint64_t)(kAlign - 1), floor_q); // a multiple of 128: segments are whole blocks
             const uint64_t take = rem <= quota ? rem : quota;
             const uint64_t at = (used + kAlign - 1) & ~(uint64_t)(kAlign - 1);

@@ -614,17 +614,24 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         ops.clear();
         size_t nj = 0;
         uint64_t used = 0;
-        std::vector<uint32_t> still;
+        // Who is served next time.  A batch cannot always serve every stream (more streams than it has floors for: 5 000 x
+        // 1 MiB at a floor of 64 KiB, 100 000 small files); round 3 then served the SAME leading streams batch after batch and
+        // the ones behind them only when those were done -- 904 of 5 000 streams hashed at the end, alone, 290 KiB a batch
+        // at 44 MB/s: kernels of 6-9 ms behind copies of 4.7 (profiles/r04_shard_trace.txt).  Now the streams a batch had
+        // no room for go FIRST in the next one, in front of those that were served at the floor; streams whose share by
+        // length exceeds the floor (the long ones that set the makespan) stay in front of both and are served every time.
+        std::vector<uint32_t> still, skipped, floor_still;
         still.reserve(active.size());
         bool full = false;
         for (uint32_t id : active) {
-            if (full) { still.push_back(id); continue; }
+            if (full) { skipped.push_back(id); continue; }
             const uint64_t rem = src[id].gpu_len - done[id];
             uint64_t quota = total_rem > (long double)S ? (uint64_t)((long double)rem * (long double)S_share / total_rem) : rem;
+            const bool at_floor = (quota & ~(uint64_t)(kAlign - 1)) < floor_q;
             quota = std::max(quota & ~(uint64_t)(kAlign - 1), floor_q); // a multiple of 128: segments are whole blocks
             const uint64_t take = rem <= quota ? rem : quota;
             const uint64_t at = (used + kAlign - 1) & ~(uint64_t)(kAlign - 1);
-            if (at + take > S) { full = true; still.push_back(id); continue; }
+            if (at + take > S) { full = true; skipped.push_back(id); continue; }
             const bool last = take == rem;
             const bool fin = last && src[id].gpu_len == src[id].len;
             Job j;
@@ -638,9 +645,17 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
             used = at + take;
             done[id] += take;
             c->stats.blocks += padded_blocks(take, fin);
-            if (!last) still.push_back(id);
+            if (!last) (at_floor ? floor_still : still).push_back(id);
         }
+        still.insert(still.end(), skipped.begin(), skipped.end());
+        still.insert(still.end(), floor_still.begin(), floor_still.end());
         active.swap(still);
+        if (getenv("SNAPHASH_TRACE_BATCHES")) {
+            uint64_t mx = 0;
+            for (size_t k = 0; k < nj; ++k) mx = std::max<uint64_t>(mx, sl.h_jobs[k].nbytes);
+            fprintf(stderr, "snaphash engine %d: batch %u: S %llu, %zu segments, %llu bytes, largest share %llu, %zu streams left behind\n", c->index, batch,
+                    (unsigned long long)S, nj, (unsigned long long)used, (unsigned long long)mx, active.size());
+        }
         const double tb2 = now_ms();
         t_plan += tb2 - tb1;
 

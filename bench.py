@@ -663,6 +663,13 @@ def main():
         dist.broadcast_object_list(box, src=0)
         return box[0]
 
+    # One process per GPU: a rank's library sees the whole job's CPU allowance (affinity mask, cgroup quota) and would size its
+    # fill pool for it.  When the allowance divided by the ranks is below what an engine takes by itself (12 fill threads),
+    # every rank is told its share (the in-library form, one ctx for all devices, divides by itself: snaphash_init).
+    if world > 1:
+        share = int(_lib.lib().snaphash_usable_cpus()) // world
+        if share < 12:
+            os.environ.setdefault("SNAPHASH_COPY_THREADS", str(max(2, share)))
     kern = {"auto": _lib.KERNEL_AUTO, "wide": _lib.KERNEL_WIDE, "split": _lib.KERNEL_SPLIT, "pair": _lib.KERNEL_PAIR,
             "quad": getattr(_lib, "KERNEL_QUAD", 4)}[args.kernel]
     numa_note = bind_to_gpu_node(device)

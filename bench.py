@@ -752,8 +752,11 @@ def main():
             step()
         fence()
         t0 = time.perf_counter()
+        step_ms = []
         for _ in range(args.steps):
+            ts = time.perf_counter()
             step()
+            step_ms.append((time.perf_counter() - ts) * 1e3)  # (this rank's own view of each step: reported beside the mean)
         fence()
         elapsed = allmax(time.perf_counter() - t0)
         e_st = ectx.stats()
@@ -900,7 +903,8 @@ def main():
                 "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": wl, "files": n_files + 1, "bytes": total_bytes, "kernel": _lib.KERNEL_NAMES.get(r_st["kernel_used"], "?"),
-                           "per_rank": per_rank_step, "tree_placement": numa_note, "tree_home": tree_home},
+                           "per_rank": per_rank_step, "tree_placement": numa_note, "tree_home": tree_home,
+                           "step_ms_rank0": {"min": round(min(step_ms), 2), "median": round(sorted(step_ms)[len(step_ms) // 2], 2), "max": round(max(step_ms), 2)}},
                 "roofline": roofline_of(k_ms, int(my_lens.sum()), r_st, args.workload, world),
                 "hbm_resident": {"what": "the same streams already in HBM (snaphash_sha512_device), every rank its share; wall per pass, MAX over ranks",
                                  "ms_per_pass": round(r_wall * 1e3, 4), "GiBps": round(total_bytes / GiB / r_wall, 3),

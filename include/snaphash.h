@@ -157,8 +157,9 @@ typedef struct snaphash_stats_ex { /* of the most recent hashing call on the ctx
 /* ---- lifetime -------------------------------------------------------------- */
 /* cfg == NULL: the calling thread's current device, defaults throughout -- unless the environment says otherwise
  * (the reference's build has neither config file nor flags for this): SNAPHASH_DEVICES = "all" or
- * "0,1,..." names the engines, SNAPHASH_HOST_THREADS = N sets the hybrid scheduler's threads (0 = none: every
- * byte on the GPU).  A non-NULL cfg is taken as it is; the environment is not consulted. */
+ * "0,1,..." names the engines, SNAPHASH_HOST_THREADS = N sets the planner's host threads (0 = none: every
+ * byte on the GPU), SNAPHASH_DEFLATE_DEPTH = N the producer's effort (deflate_depth).  A non-NULL cfg is taken as it
+ * is; the environment is not consulted (but for SNAPHASH_KEEP_RLIMIT). */
 int snaphash_init(const snaphash_config *cfg /* may be NULL */, snaphash_ctx **out);
 void snaphash_destroy(snaphash_ctx *ctx);
 int snaphash_abi_version(void);

@@ -1284,6 +1284,8 @@ try {
             if (c->staging < (1u << 16)) c->staging = 1u << 16;
             c->fill_cap = fill_cap;
             c->fd_budget = fd_budget;
+            if (!cfg && getenv("SNAPHASH_DEFLATE_DEPTH")) // a ctx made without a config is steered from the environment (snaphash.h)
+                c->deflate_depth = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(getenv("SNAPHASH_DEFLATE_DEPTH"), nullptr, 10), 4u), 256u) & ~3u;
             { // SPX: 8; a CPX/DPX partition presents fewer
                 int xcc = 0;
                 if (hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && xcc >= 1 && xcc <= 64) c->n_xcd = (uint32_t)xcc;

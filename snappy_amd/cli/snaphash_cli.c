@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include "../../include/snaphash.h"
 
@@ -127,7 +128,8 @@ int main(int argc, char **argv)
         rc = snaphash_tar_create(c, argv[3], dir, excl, &y, &len, dig);
         if (rc) ret = die(c, rc, "build");
         else {
-            FILE *f = fopen(ypath, "wb"); /* DEBIAN/ must exist, as in a build directory (build.go:219 creates it) */
+            (void)mkdir(excl, 0755); /* os.MkdirAll(debianDir, 0755), error ignored (build.go:218-219) */
+            FILE *f = fopen(ypath, "wb");
             if (!f || fwrite(y, 1, len, f) != len || fclose(f)) { perror(ypath); ret = 2; }
             for (int b = 0; !ret && b < 64; b++) printf("%02x", dig[b]);
             if (!ret) printf("  %s\n", argv[3]);

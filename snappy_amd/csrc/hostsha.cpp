@@ -409,7 +409,11 @@ int host_sha512_file_from(HostSha& s, const char* path, uint64_t offset, uint64_
 {
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return errno;
-    std::vector<uint8_t> buf(1u << 20);
+    // one read buffer per thread, kept: a fresh megabyte per file was a memset and 256 page faults in front of every small
+    // file; 256 KiB stays in the core's L2 between the copy out of the page cache and the hashing
+    constexpr size_t kBuf = 256u << 10;
+    static thread_local std::vector<uint8_t> buf;
+    if (buf.size() != kBuf) buf.resize(kBuf);
     uint64_t off = offset;
     int err = 0;
     for (;;) {

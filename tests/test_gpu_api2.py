@@ -471,6 +471,42 @@ def test_eight_engines_in_one_process(built_lib, oracle):
           (n, t8 * 1e3, t1 * 1e3, sum(e["pinned_bytes"] for e in infos) / 2**30, hbm / 2**30, [len(s) for s in cpus]))
 
 
+def test_no_stream_is_left_for_the_end(built_lib):
+    """5 000 equal streams through batches that hold 4 096 floors: every batch must serve a fair rotation -- the streams a
+    batch had no room for go first in the next one -- so that no stream's share ever grows beyond the floor.  Rounds 1-3
+    served the same leading 4 096 streams every time and hashed the other 904 at the end, alone, in shares of up to 20 x
+    the floor (kernels of 6-9 ms behind copies of 4.7: profiles/r04_rank_steps.txt).  Structural, not timed: the engine's
+    own batch trace (SNAPHASH_TRACE_BATCHES) is read back from a child process."""
+    import re
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes, hashlib\n"
+        "import numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from snappy_amd import Context, _lib\n"
+        "n, size = 5000, 256 << 10\n"
+        "host = np.random.default_rng(4).integers(0, 256, size=n * size, dtype=np.uint8)\n"
+        "ptrs = (ctypes.c_void_p * n)(*[host.ctypes.data + i * size for i in range(n)])\n"
+        "lens = (ctypes.c_uint64 * n)(*[size] * n)\n"
+        "out = ctypes.create_string_buffer(64 * n)\n"
+        "with Context(staging_bytes=64 << 20, flags=_lib.FLAG_GPU_ONLY) as c:\n"
+        "    assert _lib.lib().snaphash_sha512_buffers(c._h, ptrs, lens, n, out) == 0\n"
+        "for i in (0, 4095, 4096, 4999):\n"
+        "    assert out.raw[64 * i:64 * i + 64] == hashlib.sha512(host[i * size:(i + 1) * size]).digest(), i\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ, SNAPHASH_TRACE_BATCHES="1")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280, env=env)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode(errors="replace")[-800:]
+    batches = re.findall(r"batch (\d+): S (\d+), (\d+) segments, (\d+) bytes, largest share (\d+), (\d+) streams left behind", r.stderr.decode(errors="replace"))
+    assert len(batches) >= 15, r.stderr.decode(errors="replace")[-400:]
+    shares = [int(b[4]) for b in batches]
+    segments = [int(b[2]) for b in batches]
+    assert max(shares) <= 2 * (16 << 10), shares          # the floor from caller memory is 16 KiB: nobody ever needs more
+    assert max(segments) <= 4096 + 1 and min(segments[3:-3]) >= 3500, segments  # full batches, and all 5 000 streams within any two of them
+    assert int(batches[-1][5]) == 0
+
+
 def test_descriptor_budget_smaller_than_the_tree(built_lib, oracle, tmp_path):
     """The engine keeps a file's descriptor between the batches the file appears in (FdCache) only within what
     RLIMIT_NOFILE leaves: with a budget far below the number of files the rest is opened segment by segment, as round 3

@@ -322,7 +322,7 @@ def test_default_configuration_plans_every_call(built_lib, oracle, tmp_path):
     of similar streams stays on the GPU but for the share the spare cores can take.  hashes.yaml and the digests are the
     oracle's every time."""
     import time
-    from snappy_amd import Context, synthetic
+    from snappy_amd import Context, _lib, synthetic
     sizes = [1 << 20] * 48 + [4096, 0, 77]
     build, _ = trees.make_synthetic_tree(str(tmp_path), sizes)
     tar = os.path.join(str(tmp_path), "big.tar.gz")
@@ -355,7 +355,10 @@ def test_default_configuration_plans_every_call(built_lib, oracle, tmp_path):
         bufs = [blob[(i << 20) + i % 4096:((i + 1) << 20) + i % 4096] for i in range(n)]
         got = c.sha512_buffers(bufs)
         ex = c.stats_ex()
-        assert ex["host_bytes"] + ex["gpu_bytes"] == n << 20 and ex["gpu_bytes"] >= 0.6 * (n << 20), ex
+        cpus = int(_lib.lib().snaphash_usable_cpus())  # what the host may take depends on the cores this job may keep busy
+        host_share_bound = min(0.95, cpus * 1.5e9 / (50e9 + cpus * 1.5e9) + 0.10)
+        assert ex["host_bytes"] + ex["gpu_bytes"] == n << 20 and ex["gpu_bytes"] > 0, ex
+        assert ex["host_bytes"] <= host_share_bound * (n << 20), (ex, cpus)
         for i in (0, 1, n // 2, n - 1):
             assert got[i] == hashlib.sha512(bufs[i].tobytes()).digest()
     with Context() as c:  # the suite's default: SNAPHASH_FLAG_GPU_ONLY

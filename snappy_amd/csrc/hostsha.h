@@ -20,7 +20,9 @@ void host_sha512_update(HostSha& s, const uint8_t* p, size_t n);
 void host_sha512_final(HostSha& s, uint8_t out[64]);
 // Reads path from `offset` to EOF into s, checks that EOF is at expect_len, finalises.
 // Returns 0 or an errno.
-int host_sha512_file_from(HostSha& s, const char* path, uint64_t offset, uint64_t expect_len, uint8_t out[64]);
+// read_ahead: a second thread reads two buffers ahead of the hasher (streams of 32 MiB or more; for a caller that has a
+// core to spare: the lone archive beside its tree, not a pool that already keeps every core busy)
+int host_sha512_file_from(HostSha& s, const char* path, uint64_t offset, uint64_t expect_len, uint8_t out[64], bool read_ahead = false);
 
 // The block function exists in several spellings (portable/BMI2, AVX2 schedule, AVX-512VL schedule), picked once by
 // CPU features; tests run every one the CPU supports: variant v in [0, host_sha512_variants()), unsupported -> portable.

@@ -946,6 +946,7 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     std::atomic<int> herr{0};
     std::atomic<int64_t> herr_src{-1};
     const unsigned nh = hidx.empty() ? 0u : std::max(1u, std::min<unsigned>(plan_threads, (unsigned)hidx.size()));
+    const bool spare_cores = 2u * nh <= x->cpus; // a long file stream may take a reader thread beside its hasher (hostsha.h)
     std::vector<double> hbusy(std::max(1u, nh), 0.0);
     std::stable_sort(hidx.begin(), hidx.end(), [&](uint32_t a, uint32_t b) { return src[a].len > src[b].len; });
     auto run_host = [&](unsigned t) {
@@ -961,7 +962,7 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
                 host_sha512_update(hs, src[g].mem, src[g].len);
                 host_sha512_final(hs, digests + 64 * (size_t)g);
             } else {
-                err = host_sha512_file_from(hs, src[g].path, 0, src[g].len, digests + 64 * (size_t)g);
+                err = host_sha512_file_from(hs, src[g].path, 0, src[g].len, digests + 64 * (size_t)g, spare_cores);
             }
             if (err) {
                 int z = 0;

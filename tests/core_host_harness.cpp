@@ -85,5 +85,5 @@ extern "C" int hostsha_file(const char* path, uint64_t expect, uint8_t* out)
 {
     HostSha a;
     host_sha512_init(a);
-    return host_sha512_file_from(a, path, 0, expect, out);
+    return host_sha512_file_from(a, path, 0, expect, out, true);
 }

@@ -61,7 +61,7 @@ def test_host_sha512_of_the_hybrid_scheduler(core, tmp_path_factory):
     import hashlib
     so = str(tmp_path_factory.mktemp("core2") / "libcorehost2.so")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so,
-                           os.path.join(ROOT, "tests", "core_host_harness.cpp")])
+                           os.path.join(ROOT, "tests", "core_host_harness.cpp"), "-pthread"])
     L = ctypes.CDLL(so)
     L.hostsha_buffer.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p]
     L.hostsha_file.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
@@ -89,3 +89,11 @@ def test_host_sha512_of_the_hybrid_scheduler(core, tmp_path_factory):
     assert L.hostsha_file(str(p).encode(), len(blob) - 1, out) == errno.EIO  # grew since its size was taken
     assert L.hostsha_file(str(p).encode(), len(blob) + 1, out) == errno.EIO  # shrank
     assert L.hostsha_file(b"/nonexistent/x", 0, out) == errno.ENOENT
+    # a stream of 32 MiB or more is read by a second thread, two buffers ahead of the hasher: same digest, same size checks
+    big = tmp_path_factory.mktemp("g") / "big"
+    data = os.urandom(1 << 20) * 40 + b"tail"
+    big.write_bytes(data)
+    for _ in range(3):
+        assert L.hostsha_file(str(big).encode(), len(data), out) == 0 and out.raw == hashlib.sha512(data).digest()
+    assert L.hostsha_file(str(big).encode(), len(data) - 1, out) == errno.EIO
+    assert L.hostsha_file(str(big).encode(), len(data) + (1 << 20), out) == errno.EIO

@@ -625,7 +625,8 @@ def main():
     # SNAPHASH_BENCH_SAME_GPU=1: every rank on GPU 0, control plane and digest gather over gloo (RCCL refuses two ranks on
     # one device): how a 1-GPU box rehearses the N > 1 path.  SNAPHASH_BENCH_FORCE_DIST=1: the RCCL path with one rank.
     same_gpu = os.environ.get("SNAPHASH_BENCH_SAME_GPU") == "1"
-    device = 0 if same_gpu else local_rank
+    # LOCAL_RANK names the rank's GPU; a launcher that hands every rank ONE visible device (ordinal 0) is accommodated
+    device = 0 if same_gpu else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(device)
     force_dist = os.environ.get("SNAPHASH_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
     use_dist = world > 1 or force_dist

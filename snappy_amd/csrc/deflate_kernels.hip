@@ -309,6 +309,49 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     uint32_t best = kDfMinMatch - 1u, bdist = 0u, left = depth;
     uint32_t cur = p;
     bool more = true;
+#if !defined(SNAPHASH_DF_BRANCHY_WALK)
+    // (The inner decisions are selects, not branches: every `if` of a divergent wave costs scalar instructions for the
+    // exec mask -- the kernel issued as many of those as vector instructions -- and only the ones that skip real work
+    // (a link not wanted, a candidate that fails its check word, the extension) are worth them.)
+    while (more && left) {
+        uint32_t c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0, ncand = 0;
+#define SNAPHASH_DF_LINK(dst)                                                       \
+        if (more && ncand < left) {                                                 \
+            const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
+            const bool ok_ = d_ != 0u && p - (cur - d_) <= kDfMaxDist;              \
+            more = ok_;                                                             \
+            cur = ok_ ? cur - d_ : cur;                                             \
+            dst = ok_ ? cur : 0u;                                                   \
+            ncand += ok_ ? 1u : 0u;                                                 \
+        }
+        SNAPHASH_DF_LINK(c0_) SNAPHASH_DF_LINK(c1_) SNAPHASH_DF_LINK(c2_) SNAPHASH_DF_LINK(c3_)
+#undef SNAPHASH_DF_LINK
+        const uint32_t off = best >= 3u ? best - 3u : 0u;
+        const uint32_t mine = d32(L, p + off);
+        // the candidates' check words come through L1/L2 (the texture path), not from the data ring: the ring's LDS
+        // pipe is what bounds the walk (links, this position's words, the extensions), and the two paths run side by
+        // side (12.6 instead of 14.5 ms per 64 MiB of text)
+        const uint8_t* gb = in + (p64 - p);
+        const uint32_t k0 = *reinterpret_cast<const u32_unaligned*>(gb + c0_ + off), k1 = *reinterpret_cast<const u32_unaligned*>(gb + c1_ + off),
+                       k2 = *reinterpret_cast<const u32_unaligned*>(gb + c2_ + off), k3 = *reinterpret_cast<const u32_unaligned*>(gb + c3_ + off);
+#define SNAPHASH_DF_EVAL(k, cand, chk)                                                                         \
+        if (k < ncand && left) {                                                                                \
+            --left;                                                                                             \
+            bool go = true;                                                                                     \
+            if (best >= 3u) go = (off == best - 3u) ? (chk == mine) : (d32(L, cand + best - 3u) == d32(L, p + best - 3u)); \
+            if (go) {                                                                                           \
+                const uint32_t l = extend_match(L, p, cand, maxl);                                              \
+                const bool better = l > best;                                                                   \
+                const uint32_t cut = (l >= kDfNice || l >= maxl) ? 0u : ((l >= kDfGood && left > depth / 4u) ? depth / 4u : left); \
+                bdist = better ? p - cand : bdist;                                                              \
+                left = better ? cut : left;                                                                     \
+                best = better ? l : best;                                                                       \
+            }                                                                                                   \
+        }
+        SNAPHASH_DF_EVAL(0u, c0_, k0) SNAPHASH_DF_EVAL(1u, c1_, k1) SNAPHASH_DF_EVAL(2u, c2_, k2) SNAPHASH_DF_EVAL(3u, c3_, k3)
+#undef SNAPHASH_DF_EVAL
+    }
+#else // round 3's branches (make branchy, for A/B)
     while (more && left) {
         uint32_t c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0, ncand = 0;
 #define SNAPHASH_DF_LINK(dst)                                                       \
@@ -345,6 +388,7 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
         SNAPHASH_DF_EVAL(0u, c0_, k0) SNAPHASH_DF_EVAL(1u, c1_, k1) SNAPHASH_DF_EVAL(2u, c2_, k2) SNAPHASH_DF_EVAL(3u, c3_, k3)
 #undef SNAPHASH_DF_EVAL
     }
+#endif
     if (best == 3u && bdist > kDfTooFar) best = 0u;
     return best >= kDfMinMatch ? res_pack(best, bdist, byte) : res_pack(0u, 0u, byte);
 }

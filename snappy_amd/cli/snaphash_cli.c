@@ -32,7 +32,7 @@ static int usage(void)
 {
     fprintf(stderr, "usage: snaphash [-d DEV,...] [-t HOST_THREADS] [-g] [-z DEPTH] [-s] hash FILE... | tree DIR TAR | write DIR TAR |\n"
                     "       verify DIR YAML [TAR] | build DIR OUT.tar.gz | gzip IN OUT.gz | cmp A B [A B ...] |\n"
-                    "       dirupdated DIR_A DIR_B [PREFIX]\n"
+                    "       dirupdated DIR_A DIR_B [PREFIX] | plan FILE... (what the planner would do; no device needed)\n"
                     "       -g: every byte through the HIP kernels (SNAPHASH_FLAG_GPU_ONLY); default: every call is planned\n"
                     "       -z DEPTH: effort of `build` / `gzip` (hash-chain links per position; default 32, 64 = gzip -9's class)\n");
     return 2;
@@ -79,6 +79,30 @@ int main(int argc, char **argv)
     argc -= a - 1;
     argv += a - 1;
     if (argc < 3) return usage();
+    if (!strcmp(argv[1], "plan")) { /* what the planner would do with these files: no device is touched */
+        size_t n = (size_t)argc - 2;
+        uint64_t *lens = malloc(n * sizeof *lens);
+        uint8_t *on_host = malloc(n);
+        for (size_t i = 0; i < n; i++) {
+            struct stat st;
+            if (stat(argv[2 + i], &st) != 0) { perror(argv[2 + i]); return 2; }
+            lens[i] = (uint64_t)st.st_size;
+        }
+        snaphash_plan_model pm;
+        memset(&pm, 0, sizeof pm);
+        pm.struct_size = sizeof pm;
+        pm.n_devices = cfg.n_devices ? cfg.n_devices : 1;
+        pm.host_threads = cfg.host_threads;
+        pm.from_files = 1;
+        int prc = snaphash_plan_streams(lens, n, &pm, on_host);
+        if (prc) { fprintf(stderr, "snaphash: plan: %s\n", snaphash_strerror(prc)); return 1; }
+        for (size_t i = 0; i < n; i++) printf("%s  %s\n", on_host[i] ? "host" : "gpu ", argv[2 + i]);
+        fprintf(stderr, "snaphash: plan for %u usable CPUs: %llu streams / %llu B on %u host thread(s), modelled %.3f ms; GPU part modelled %.3f ms\n",
+                snaphash_usable_cpus(), (unsigned long long)pm.host_streams, (unsigned long long)pm.host_bytes, pm.host_threads_used,
+                pm.host_seconds * 1e3, pm.gpu_seconds * 1e3);
+        free(lens); free(on_host);
+        return 0;
+    }
     snaphash_ctx *c = NULL;
     /* no engine option given: NULL config, so that SNAPHASH_DEVICES / SNAPHASH_HOST_THREADS apply (snaphash.h) */
     int rc = snaphash_init((cfg.n_devices || cfg.host_threads || cfg.flags || cfg.deflate_depth) ? &cfg : NULL, &c);

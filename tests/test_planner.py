@@ -138,3 +138,21 @@ def test_cgroup_cpu_quota_on_fake_trees(built_lib, tmp_path):
     proc0.write_text("0::/\n")
     assert L.snaphash_cgroup_cpu_quota(str(tmp_path / "nowhere").encode(), str(proc0).encode()) == 0
     assert 1 <= L.snaphash_usable_cpus() <= len(os.sched_getaffinity(0))
+
+
+def test_cli_plan_verb_needs_no_device(built_lib, tmp_path):
+    """`snaphash plan FILE...` (snappy_amd/cli/snaphash_cli.c): the plan of a call from plain C, over snaphash_plan_streams --
+    it touches no device, so it runs here."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "snappy_amd", "bin", "snaphash")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "snappy_amd", "csrc")])
+    small, big = tmp_path / "small.bin", tmp_path / "big.bin"
+    small.write_bytes(b"x" * 3000)
+    big.write_bytes(b"y" * (24 << 20))
+    r = subprocess.run([exe, "-t", "4", "plan", str(small), str(big)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 0, r.stderr.decode()
+    lines = r.stdout.decode().splitlines()
+    assert lines[1].startswith("host") and lines[1].endswith("big.bin")   # 24 MiB alone on the GPU: 0.57 s; on a host core 18 ms
+    assert lines[0].split()[0] in ("gpu", "host") and b"modelled" in r.stderr

@@ -21,7 +21,9 @@ struct Job {
 static_assert(sizeof(Job) == 32, "Job is 32 bytes");
 
 hipError_t launch_wide(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
-hipError_t launch_pair(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
+// staged: the launch is one batch of a staged pass (the same code under the name sha512_pair_staged_kernel, so that a
+// profile of bench.py keeps the HBM-resident launches apart from them)
+hipError_t launch_pair(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s, bool staged = false);
 hipError_t launch_split(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
 hipError_t launch_quad(const Job* d_jobs, uint32_t njobs, uint64_t* d_state, uint8_t* d_digests, hipStream_t s);
 bool have_quad_kernel(); // built with `make QUAD=1` only

@@ -330,10 +330,10 @@ constexpr uint64_t kSplitMinBlocks = 32;
 
 uint64_t job_blocks(const Job& j) { return (j.nbytes >> 7) + 1; }
 
-hipError_t launch_kernel(uint32_t k, const Job* d_jobs, size_t n, DevCtx* c, uint8_t* d_digests)
+hipError_t launch_kernel(uint32_t k, const Job* d_jobs, size_t n, DevCtx* c, uint8_t* d_digests, bool staged)
 {
     if (k == SNAPHASH_KERNEL_QUAD) return launch_quad(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
-    if (k == SNAPHASH_KERNEL_PAIR) return launch_pair(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
+    if (k == SNAPHASH_KERNEL_PAIR) return launch_pair(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream, staged);
     if (k == SNAPHASH_KERNEL_SPLIT) return launch_split(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
     return launch_wide(d_jobs, (uint32_t)n, c->d_state, d_digests, c->stream);
 }
@@ -386,8 +386,9 @@ int launch_jobs(DevCtx* c, Job* h_jobs, Job* d_jobs, size_t n, uint8_t* d_digest
     EventPair* ev = next_events(c, 0);
     if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
     HIP_TRY(c, hipEventRecord(ev->a, c->stream));
-    hipError_t e = launch_kernel(k_head, d_jobs, head, c, d_digests);
-    if (e == hipSuccess && head < n) e = launch_kernel(k_tail, d_jobs + head, n - head, c, d_digests);
+    const bool staged = copied != nullptr; // the job table came through a staging slot
+    hipError_t e = launch_kernel(k_head, d_jobs, head, c, d_digests, staged);
+    if (e == hipSuccess && head < n) e = launch_kernel(k_tail, d_jobs + head, n - head, c, d_digests, staged);
     if (e != hipSuccess) return fail(c, SNAPHASH_EDEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
     HIP_TRY(c, hipEventRecord(ev->b, c->stream));
     c->stats.launches += (head < n) ? 2 : 1;

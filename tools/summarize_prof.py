@@ -23,9 +23,10 @@ os.makedirs(out, exist_ok=True)
 ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(out, tag + "_kernel_stats.csv"))
-# The default command launches the hashing kernel two ways: ONE launch over the whole resident tree (the roofline object:
-# 157 workgroups for 10 001 streams) and the staged batches of the end-to-end pass (4 096 streams = 64 workgroups each).
-# rocprofv3's --stats averages them under one name; the per-launch trace separates them by grid size.
+# The default command launches the hashing code two ways: ONE launch over the whole resident tree (the roofline object:
+# 157 workgroups for 10 001 streams, kernel sha512_split_kernel<true>) and the staged batches of the end-to-end pass
+# (4 096 streams = 64 workgroups each, the same code under the name sha512_pair_staged_kernel), so rocprofv3's --stats
+# lists them apart; the per-launch trace, split by grid size, is kept as well.
 kt = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
 if kt:
     groups = collections.defaultdict(list)
@@ -40,13 +41,13 @@ pmc = {}
 kname = None
 resident_grid = None
 if kt:
-    big = [(max(v), g) for (k, g, w), v in groups.items() if "sha512" in k]
+    big = [(max(v), g) for (k, g, w), v in groups.items() if "sha512" in k and "staged" not in k]
     resident_grid = max(big)[1] if big else None
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "sha512" in r["Kernel_Name"] and (resident_grid is None or r["Grid_Size"] == resident_grid):  # the resident launch only
+            if "sha512" in r["Kernel_Name"] and "staged" not in r["Kernel_Name"] and (resident_grid is None or r["Grid_Size"] == resident_grid):  # the resident launch only
                 kn = r["Kernel_Name"]
                 kname = ("sha512_split_kernel_true" if "<true>" in kn or "ILb1" in kn else "sha512_split_kernel_false") if "split" in kn else "sha512_wide_kernel"
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -44,8 +44,10 @@ void host_sha512_resume(HostSha& s, const uint64_t H[8], uint64_t total_prev)
 }
 
 // One 128-byte block: FIPS 180-4 sec. 6.4.2, rounds fully unrolled over a 16-word rolling schedule.
-// (Same function as compress_block in sha512_core.h; spelled for a host core: native 64-bit rotates,
-// and a BMI2 clone where the CPU has rorx.)
+// (Same function as compress_block in sha512_core.h; spelled for a host core: native 64-bit rotates.  Baseline x86-64
+// only: a CPU with rorx also has AVX2 and takes blocks_avx2 below, so a BMI2 clone of this one bought nothing -- and
+// target_clones makes an IFUNC, whose resolver runs before any runtime is up: the ThreadSanitizer build of
+// tests/tsan_host.cpp died in it.)
 #define HS_ROTR(x, n) (((x) >> (n)) | ((x) << (64 - (n))))
 #define HS_S0(x) (HS_ROTR(x, 28) ^ HS_ROTR(x, 34) ^ HS_ROTR(x, 39))
 #define HS_S1(x) (HS_ROTR(x, 14) ^ HS_ROTR(x, 18) ^ HS_ROTR(x, 41))
@@ -103,7 +105,7 @@ void host_sha512_resume(HostSha& s, const uint64_t H[8], uint64_t total_prev)
     } while (0)
 #endif
 
-__attribute__((target_clones("default", "bmi2"))) static void blocks(uint64_t H[8], const uint8_t* p, size_t nblocks)
+static void blocks(uint64_t H[8], const uint8_t* p, size_t nblocks)
 {
     uint64_t a = H[0], b = H[1], c = H[2], d = H[3], e = H[4], f = H[5], g = H[6], h = H[7];
     for (; nblocks; --nblocks, p += 128) {

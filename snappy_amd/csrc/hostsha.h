@@ -24,7 +24,7 @@ void host_sha512_final(HostSha& s, uint8_t out[64]);
 // core to spare: the lone archive beside its tree, not a pool that already keeps every core busy)
 int host_sha512_file_from(HostSha& s, const char* path, uint64_t offset, uint64_t expect_len, uint8_t out[64], bool read_ahead = false);
 
-// The block function exists in several spellings (portable/BMI2, AVX2 schedule, AVX-512VL schedule), picked once by
+// The block function exists in several spellings (portable, AVX2 schedule, AVX-512VL schedule), picked once by
 // CPU features; tests run every one the CPU supports: variant v in [0, host_sha512_variants()), unsupported -> portable.
 int host_sha512_variants();
 void host_sha512_blocks_variant(int v, uint64_t H[8], const uint8_t* p, size_t nblocks);

@@ -267,6 +267,36 @@ def test_hostpass_under_asan_and_ubsan(tmp_path):
     assert b"asan driver ok" in r.stdout
 
 
+
+def test_threaded_host_code_under_tsan(tmp_path):
+    """What the library runs on more than one host thread -- the level-wise walk, the ranged YAML emitter, the pool of
+    staging-fill threads, the read-ahead reader of a long host-hashed file -- built with -fsanitize=thread
+    (tests/tsan_host.cpp): no report, every result equal to the single-threaded one."""
+    import subprocess
+    exe = str(tmp_path / "tsan_host")
+    src = [os.path.join(ROOT, "snappy_amd", "csrc", f) for f in
+           ("hostpass.cpp", "yamlscalar.cpp", "walk.cpp", "hostfill.cpp", "hostsha.cpp", "planner.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-o", exe,
+                           os.path.join(ROOT, "tests", "tsan_host.cpp")] + src + ["-pthread"])
+    build = tmp_path / "build"
+    for d in range(40):
+        for e in range(3):
+            p = build / ("d%02d" % d) / ("e%d" % e)
+            p.mkdir(parents=True)
+            for f in range(40):
+                (p / ("f%03d" % f)).write_bytes(b"x" * (f * 13))
+    big = tmp_path / "big.bin"
+    big.write_bytes(os.urandom(1 << 20) * 40)
+    cmd = [exe, str(build), str(big)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if r.returncode != 0 and b"unexpected memory mapping" in r.stderr:  # the sanitizer runtime against this kernel's ASLR
+        r = subprocess.run(["setarch", "x86_64", "-R"] + cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        if r.returncode != 0 and b"ThreadSanitizer: data race" not in r.stderr and b"tsan driver" not in r.stdout and b"unexpected memory mapping" in r.stderr:
+            pytest.skip("ThreadSanitizer cannot map its shadow on this kernel")
+    assert r.returncode == 0 and b"WARNING: ThreadSanitizer" not in r.stderr, (r.returncode, r.stderr.decode()[-4000:])
+    assert b"tsan driver ok" in r.stdout
+
+
 _UNLISTABLE_CHILD = r'''
 import ctypes, sys
 d, build, tar = sys.argv[1], sys.argv[2].encode(), sys.argv[3].encode()

@@ -1,0 +1,109 @@
+// Test-only driver: the library's multi-threaded HOST code under ThreadSanitizer (CPU build; GPU sanitizers are not
+// available on the pool).  What runs on more than one thread beside the kernels: the level-wise parallel walk
+// (walk.cpp), the ranged YAML emitter (hostpass.cpp), the persistent pool of staging-fill threads (hostfill.cpp
+// FillPool), the read-ahead reader of one long host-hashed file (hostsha.cpp) and the thread sets of a planned host
+// part (ThreadJoiner).  Exit code 0 = no report, every result equal to the single-threaded one.
+//
+// usage: tsan_host BUILD_DIR BIG_FILE
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <string>
+#include <vector>
+
+#include "../snappy_amd/csrc/hostfill.h"
+#include "../snappy_amd/csrc/hostpass.h"
+#include "../snappy_amd/csrc/hostsha.h"
+
+using namespace snaphash;
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) return 2;
+    // 1. the walk, several times over (its worker sets are created per call), and the emitter over its records
+    std::vector<Record> first;
+    std::string first_yaml;
+    for (int round = 0; round < 4; ++round) {
+        std::vector<Record> recs;
+        int en = 0;
+        if (walk_tree(argv[1], recs, &en) != SNAPHASH_OK) return 3;
+        if (recs.size() < 4096) return 4; // below that neither the walk nor the emitter goes parallel
+        std::vector<uint8_t> dig(64 * (recs.size() + 1));
+        for (size_t i = 0; i < dig.size(); ++i) dig[i] = (uint8_t)(i * 131u >> 3);
+        std::string y;
+        if (emit_yaml(recs, dig.data(), dig.data() + 64, y) != SNAPHASH_OK) return 5;
+        if (round == 0) {
+            first = recs;
+            first_yaml = y;
+            ParsedHashes ph;
+            if (parse_yaml(y.data(), y.size(), ph) != SNAPHASH_OK || ph.files.size() != recs.size()) return 6;
+            for (size_t i = 0; i < recs.size(); ++i)
+                if (ph.files[i].name != recs[i].name) return 7;
+        } else {
+            if (recs.size() != first.size() || y != first_yaml) return 8;
+            for (size_t i = 0; i < recs.size(); ++i)
+                if (recs[i].name != first[i].name || recs[i].size != first[i].size || recs[i].st_mode != first[i].st_mode) return 9;
+        }
+    }
+
+    // 2. the fill pool: many short jobs back to back (the epoch hand-over is where a lost wake-up or a stale fn_
+    //    would show), resized in between, destroyed with threads parked
+    {
+        FillPool pool;
+        pool.configure(6, {});
+        std::vector<uint32_t> slots(5000);
+        for (int job = 0; job < 300; ++job) {
+            const size_t n = 1 + (size_t)(job * 37 % 5000);
+            std::atomic<size_t> calls{0};
+            const std::function<void(size_t)> fn = [&](size_t i) {
+                slots[i] = (uint32_t)(i * 2654435761u) + (uint32_t)job;
+                calls.fetch_add(1, std::memory_order_relaxed);
+            };
+            pool.parallel_for(n, 1 + job % 7, fn);
+            if (calls.load() != n) return 10;
+            for (size_t i = 0; i < n; ++i)
+                if (slots[i] != (uint32_t)(i * 2654435761u) + (uint32_t)job) return 11;
+            if (job == 150) pool.configure(3, {});
+            if (job == 220) pool.configure(8, {});
+        }
+        // copies into a buffer the pool's threads share, disjoint ranges, non-temporal path included
+        std::vector<uint8_t> src(8u << 20), dst(8u << 20);
+        for (size_t i = 0; i < src.size(); ++i) src[i] = (uint8_t)(i * 7u + (i >> 11));
+        const std::function<void(size_t)> cp = [&](size_t i) { copy_to_staging(dst.data() + i * (256u << 10), src.data() + i * (256u << 10), 256u << 10); };
+        pool.parallel_for(32, 6, cp);
+        if (memcmp(src.data(), dst.data(), src.size()) != 0) return 12;
+    }
+
+    // 3. one long file on a host thread with the reader thread ahead of it, against the plain loop
+    {
+        uint8_t a[64], b[64];
+        HostSha s1, s2;
+        host_sha512_init(s1);
+        host_sha512_init(s2);
+        FILE* f = fopen(argv[2], "rb");
+        if (!f) return 13;
+        fseek(f, 0, SEEK_END);
+        const uint64_t len = (uint64_t)ftell(f);
+        fclose(f);
+        if (len < (32u << 20)) return 14; // the read-ahead starts at 32 MiB
+        if (host_sha512_file_from(s1, argv[2], 0, len, a, false) != 0) return 15;
+        if (host_sha512_file_from(s2, argv[2], 0, len, b, true) != 0) return 16;
+        if (memcmp(a, b, 64) != 0) return 17;
+        // and two of them at once, as two host threads of a planned call would run them
+        uint8_t c[64], d[64];
+        int rc1 = -1, rc2 = -1;
+        {
+            ThreadJoiner tj;
+            tj.th.emplace_back([&] { HostSha s; host_sha512_init(s); rc1 = host_sha512_file_from(s, argv[2], 0, len, c, true); });
+            tj.th.emplace_back([&] { HostSha s; host_sha512_init(s); rc2 = host_sha512_file_from(s, argv[2], 0, len, d, true); });
+        }
+        if (rc1 != 0 || rc2 != 0 || memcmp(a, c, 64) != 0 || memcmp(a, d, 64) != 0) return 18;
+        // a file that is shorter than the caller says: the reader thread must stop and be joined, an error come back
+        HostSha s3;
+        host_sha512_init(s3);
+        if (host_sha512_file_from(s3, argv[2], 0, len + 4096, a, true) == 0) return 19;
+    }
+    printf("tsan driver ok\n");
+    return 0;
+}

@@ -117,6 +117,18 @@ def test_crc32_and_combine_match_zlib(f3):
     for cut in (0, 1, 4096, 150000, 299999, 300000):
         c1, c2 = zlib.crc32(blob[:cut]), zlib.crc32(blob[cut:])
         assert f3.f3_crc32_combine(c1, c2, len(blob) - cut) == zlib.crc32(blob)
+    # the carry-less-multiplication form (tarpack.cpp crc32_clmul: 256 bytes and more) at every length class modulo 64 and
+    # 16, every start alignment, and continued from a running value
+    for a in range(0, 17):
+        for n in list(range(240, 420)) + [1000, 4096 + a, 65536 - a, 200003]:
+            assert f3.f3_crc32(0, blob[a:a + n], n) == zlib.crc32(blob[a:a + n]), (a, n)
+    run = 0
+    ref = 0
+    for a, b in ((0, 300), (300, 1324), (1324, 1325), (1325, 70000), (70000, 300000)):
+        run = f3.f3_crc32(run, blob[a:b], b - a)
+        ref = zlib.crc32(blob[a:b], ref)
+        assert run == ref
+    assert f3.f3_crc32(0, bytes(4 << 20), 4 << 20) == zlib.crc32(bytes(4 << 20))
 
 
 def _make_tree(root):

@@ -93,6 +93,15 @@ def test_tar_create_matches_tarfile_view_of_the_tree(built_lib, tmp_path):
         if m.isreg():
             assert tf.extractfile(m).read() == files[m.name[2:]], m.name
     assert tf.getmember("./usr/bin/link").linkname == "foo" and tf.getmember("./usr/bin/foo").mode & 0o777 == 0o755
+    # os.Create over an archive that is already there, longer and shorter than the new one: the library overwrites from
+    # offset 0 and sets the length at the END of the pass (targz.inc), the result must be the same bytes as on a fresh path
+    with Context() as c:
+        for old in (os.urandom(len(raw) + 70001), b"short", raw[:len(raw) // 2] + b"x" * 11):
+            with open(out, "wb") as f:
+                f.write(old)
+            _, digest2 = c.tar_create(out, root, root + "/DEBIAN")
+            assert open(out, "rb").read() == raw and digest2 == digest
+        assert c.tar_create("/dev/null.gz" if os.path.exists("/dev/null.gz") else out, root, root + "/DEBIAN")[1] == digest
     with pytest.raises(Exception):
         with Context() as c:
             c.tar_create(str(tmp_path / "data.tar.xz"), root)  # "unknown compression extension" for anything but .gz here

@@ -268,6 +268,9 @@ typedef struct snaphash_targz_stats { /* of the most recent snaphash_tar_create 
  * kernels hash each regular file out of the staged tar stream, the archive digest is taken over the
  * bytes written, and *yaml_out receives hashes.yaml (snaphash_free); exclude_prefix must then be
  * writeHashes' own rule.  archive_digest (may be NULL): the 64 raw bytes of SHA-512(tarname).
+ * tarname is created as os.Create does (deb.go:264) with one difference in timing: a file already there is
+ * overwritten from offset 0 and cut to the new length when the last byte is written, not emptied first (emptying a
+ * previous 250 MiB archive stalled the whole pipeline for 25-30 ms); it is unlinked when the pass fails.
  * On a ctx with several devices the producer runs on the first engine: the pass is bound by the one stream that
  * cannot be split -- the SHA-512 of the archive on a host core, 1.4 GB/s -- which a single PCIe link outruns 40x. */
 int snaphash_tar_create(snaphash_ctx *ctx, const char *tarname, const char *source_dir, const char *exclude_prefix,

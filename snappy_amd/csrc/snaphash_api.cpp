@@ -135,6 +135,7 @@ struct DevCtx {
     hipStream_t z_stream = nullptr;          // the compressor's stream
     hipStream_t z2_stream = nullptr;         // concatenation of a finished piece and its way back to the host
     std::vector<hipEvent_t> z_ev;            // "the sizes of piece k are on the host"
+    std::vector<hipEvent_t> z_part_ev;       // "part k of the pass's first slot is in HBM" (targz.inc)
     size_t z_chunks = 0;
 
     std::vector<EventPair> ev_pool;
@@ -1165,6 +1166,7 @@ static void destroy_dev(DevCtx* c)
     if (c->z_stream) (void)hipStreamDestroy(c->z_stream);
     if (c->z2_stream) (void)hipStreamDestroy(c->z2_stream);
     for (hipEvent_t e : c->z_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->z_part_ev) (void)hipEventDestroy(e);
     for (EventPair& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }

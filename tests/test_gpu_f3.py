@@ -249,6 +249,64 @@ def test_tar_create_slot_boundaries_random_trees(built_lib, oracle, tmp_path):
             c.close()
 
 
+def test_first_slot_goes_to_the_compressor_in_parts(built_lib, oracle, tmp_path):
+    """A pass's first slot (default staging: 256 MiB) is read, copied and compressed 64 MiB at a time (targz.inc, in_parts):
+    the first chunk kernel runs while the rest of the slot is still on its way.  Members straddle both part boundaries;
+    the bytes must equal the serial CPU model's over the same tar stream, inflate to it, and not depend on what the
+    staging buffer held before (a different tree goes through the same ctx in between)."""
+    import ctypes
+    import subprocess
+    from snappy_amd import Context
+    rng = np.random.default_rng(77)
+    so = str(tmp_path / "libf3host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "f3_host_harness.cpp")])
+    L = ctypes.CDLL(so)
+    L.f3_tar_stream.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.f3_model_gzip2.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.f3_model_gzip2.restype = ctypes.c_void_p
+    L.f3_free.argtypes = [ctypes.c_void_p]
+    MiB = 1 << 20
+    words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(500)]
+    text = b" ".join(words[int(i)] for i in rng.zipf(1.3, size=300000) % 500)
+
+    def content(kind, size):
+        if kind == "random":
+            return rng.integers(0, 256, size=size, dtype=np.uint8).tobytes()
+        off = int(rng.integers(0, len(text) - 1))
+        return ((text[off:] + text) * (size // len(text) + 2))[:size]
+
+    def make(root, spec):
+        os.makedirs(os.path.join(root, "DEBIAN"))
+        open(os.path.join(root, "DEBIAN", "control"), "w").write("Package: parts\n")
+        for name, kind, size in spec:
+            with open(os.path.join(root, name), "wb") as f:
+                f.write(content(kind, size))
+
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    make(a, [("f0", "text", 63 * MiB - 700), ("f1", "random", 5 * MiB + 13), ("f2", "random", 60 * MiB + 511), ("f3", "text", 10 * MiB), ("f4", "text", 0), ("f5", "random", 1)])
+    make(b, [("g0", "random", 90 * MiB), ("g1", "text", 20 * MiB + 5)])
+    p, n = ctypes.c_void_p(), ctypes.c_size_t()
+    assert L.f3_tar_stream(a.encode(), (a + "/DEBIAN").encode(), ctypes.byref(p), ctypes.byref(n)) == 0
+    want_tar = ctypes.string_at(p.value, n.value)
+    L.f3_free(p)
+    assert 2 * 64 * MiB < len(want_tar) < 256 * MiB  # three parts, one slot
+    out = str(tmp_path / "o.tar.gz")
+    with Context() as c:
+        y1, d1 = c.tar_create(out, a, a + "/DEBIAN", with_hashes=True)
+        raw1 = open(out, "rb").read()
+        c.tar_create(str(tmp_path / "other.tar.gz"), b, b + "/DEBIAN", with_hashes=True)
+        y3, d3 = c.tar_create(out, a, a + "/DEBIAN", with_hashes=True)
+        raw3 = open(out, "rb").read()
+    assert raw1 == raw3 and d1 == d3 and y1 == y3
+    assert hashlib.sha512(raw1).digest() == d1 and y1 == oracle.hashes_yaml(a, out)
+    assert gzip.decompress(raw1) == want_tar
+    m = ctypes.c_size_t()
+    q = L.f3_model_gzip2(want_tar, len(want_tar), 0, ctypes.byref(m))  # one slot = one piece of the model
+    model = ctypes.string_at(q, m.value)
+    L.f3_free(q)
+    assert raw1 == model
+
+
 def test_tarcreate_as_the_reference_tests_it(built_lib, tmp_path):
     """clickdeb/deb_test.go:160-205 (TestTarCreate) against the mirror of the Go function, snappy_amd.clickdeb.tarCreate:
     the same tree, the same exclude FUNCTION (a suffix rule, not a prefix), the same assertions on `tar tvf` -- with

@@ -114,13 +114,15 @@ typedef struct snaphash_config {
                                stream advances at ~44 MB/s on the GPU whatever surrounds it and at ~1.4 GB/s on a host
                                core (the library's own vectorised SHA-512, hostsha.cpp); a launch costs ~0.15 ms.  Every
                                call is therefore planned: modelled GPU makespan = latency + max(longest stream / 44 MB/s,
-                               bytes / PCIe link), host makespan = LPT of the moved streams over the host threads; streams
+                               bytes / PCIe link, fill work / fill threads), host makespan = LPT of the moved streams over
+                               the host threads, and what all threads together ask of the cores; streams
                                move to host threads, longest first and concurrently with the GPU batch, while that
-                               shortens max(GPU, host) -- the package's data.tar.gz (build.go:222), a 1 GiB member -- and
+                               shortens the largest of the three -- the package's data.tar.gz (build.go:222), a 1 GiB member,
+                               the few big files of a tree of many small ones, a share of a tree the link bounds -- and
                                a batch the host alone finishes sooner than any split (a lone file, a small tree dominated
                                by one member) runs on host threads whole: no call is slower than the reference's loop.
-                                 0 (default) = as many host threads as this process may keep busy (affinity mask capped
-                                     by the cgroup CPU quota), less the staging fill threads while there is a GPU part;
+                                 0 (default) = the best of every host thread count up to what this process may keep busy
+                                     (affinity mask capped by the cgroup CPU quota); the staging fill keeps its threads;
                                  N > 0 = exactly N;
                                  SNAPHASH_FLAG_GPU_ONLY = no planning, every byte through the HIP kernels.
                                snaphash_stats_ex says which bytes went where.  Not a fallback: init still fails

@@ -28,13 +28,20 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
     if (n == 0) return res;
     const unsigned nd = std::max(1u, m.n_devices);
     const double link = (m.gpu_link > 0 ? m.gpu_link : (m.from_files ? 54e9 : 55e9)) * nd;
-    const double g_stream = m.gpu_per_stream > 0 ? m.gpu_per_stream : (m.from_files ? 0.5e-6 : 0.15e-6);
-    const double h_stream = m.host_per_stream > 0 ? m.host_per_stream : (m.from_files ? 4e-6 : 0.05e-6);
+    const double g_plan = m.gpu_per_stream > 0 ? m.gpu_per_stream : 0.15e-6;
+    const double f_rate = m.fill_rate > 0 ? m.fill_rate : (m.from_files ? 6.5e9 : 9e9);
+    const double f_stream = m.fill_per_stream > 0 ? m.fill_per_stream : (m.from_files ? 10e-6 : 0.3e-6);
     const double h_rate = m.host_rate > 0 ? m.host_rate : 1.4e9;
     const unsigned cpus = std::max(1u, m.cpus);
-    const unsigned fill = m.fill_threads * nd;
-    const unsigned h_mixed = m.host_threads ? m.host_threads : (cpus > fill + 1u ? cpus - fill - 1u : 1u); // beside a GPU part: its fill threads and the engine's own thread keep their cores
-    const unsigned h_alone = m.host_threads ? m.host_threads : cpus;                            // no GPU part: every core hashes
+    const unsigned fill = std::max(1u, m.fill_threads) * nd;
+    const unsigned h_base = cpus > fill + 1u ? cpus - fill - 1u : 1u; // beside a GPU part at full fill: its fill threads and the engine's own thread keep their cores
+    const unsigned h_alone = m.host_threads ? m.host_threads : cpus;   // no GPU part: every core hashes
+    // a stream's fixed cost on a host thread: for files open + fstat + close, which do not scale (the threads meet on the
+    // directories' reference counts): 4 us alone, ~20 us each with sixteen at it (100 000 files, profiles/r04_c5_on_disk_tree.txt)
+    auto h_stream = [&](unsigned threads) {
+        if (m.host_per_stream > 0) return m.host_per_stream;
+        return m.from_files ? 4e-6 * std::max(1.0, (double)threads / 3.0) : 0.05e-6;
+    };
 
     std::vector<uint32_t> order(n);
     for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
@@ -44,7 +51,8 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
         suffix[k] = suffix[k + 1] + (double)lens[order[k]];
         suffix_blocks[k] = suffix_blocks[k + 1] + (double)blocks_of(lens[order[k]]);
     }
-    auto host_cost = [&](size_t k) { return (double)lens[order[k]] / h_rate + h_stream; };
+    // CPU time the staging fill of streams order[k..] costs (all fill threads together)
+    auto fill_work = [&](size_t k) { return k >= n ? 0.0 : suffix[k] / f_rate + (double)(n - k) * f_stream; };
     // modelled time of the GPU part when streams order[k..] stay on it
     auto gpu_time = [&](size_t k) {
         if (k >= n) return 0.0;
@@ -54,46 +62,57 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
         if (left <= kPairMaxStreams) pair = suffix_blocks[k] >= (double)kPairMinBlocks * (double)left;
         else pair = b0 >= kPairMinBlocks && b0 >= 8 * blocks_of(lens[order[k + kPairMaxStreams - 1]]);
         const double rate = pair ? m.gpu_pair_rate : m.gpu_wide_rate;
-        return m.gpu_latency + (double)left * g_stream + std::max((double)lens[order[k]] / rate, suffix[k] / link);
+        return m.gpu_latency + (double)left * g_plan + std::max({(double)lens[order[k]] / rate, suffix[k] / link, fill_work(k) / (double)fill});
     };
 
-    // the k longest streams on h_mixed host threads (LPT), the rest on the GPU: G falls and H rises with k
-    double best = gpu_time(0), best_host = 0;
+    // The k longest streams on h host threads (LPT), the rest on the GPU: G falls and H rises with k.  The fill threads
+    // keep their count whatever h is -- they are busy in bursts, and taking cores from them cost more than it gave
+    // (214 ms against 179 on config 2, profiles/r04_default_probe.txt) -- so h + fill may exceed the cores; what binds
+    // then is the cores' total: (fill work + host work) / cpus.
+    const double gpu_alone = gpu_time(0);
+    double best = gpu_alone, best_host = 0;
     size_t best_k = 0;
-    {
+    unsigned threads = h_base;
+    const unsigned h_last = m.host_threads ? m.host_threads : (cpus > 2u ? std::max(h_base, cpus - 2u) : h_base);
+    for (unsigned h = m.host_threads ? m.host_threads : h_base; h <= h_last; ++h) {
+        const double hs = h_stream(h);
         MinHeap pool;
-        for (unsigned t = 0; t < h_mixed; ++t) pool.push(0.0);
-        double host_makespan = 0;
+        for (unsigned t = 0; t < h; ++t) pool.push(0.0);
+        double host_makespan = 0, host_work = 0;
         for (size_t k = 0; k < n; ++k) {
-            const double t = pool.top() + host_cost(k);
+            const double c = (double)lens[order[k]] / h_rate + hs;
+            const double t = pool.top() + c;
             pool.pop();
             pool.push(t);
+            host_work += c;
             host_makespan = std::max(host_makespan, t);
-            const double mk = std::max(gpu_time(k + 1), host_makespan);
-            if (mk < best * 0.98) { best = mk; best_k = k + 1; best_host = host_makespan; } // move only for a real gain
-            if (host_makespan > best) break;                                               // H only grows from here
+            const double g = gpu_time(k + 1);
+            const double cores = k + 1 < n ? (fill_work(k + 1) + host_work + g) / (double)cpus : 0.0; // (+ g: the engine's own thread)
+            const double mk = std::max({g, host_makespan, cores});
+            if (mk < best * 0.98) { best = mk; best_k = k + 1; best_host = host_makespan; threads = h; } // move only for a real gain
+            if (host_makespan > best) break;                                                           // H only grows from here
         }
     }
     // A GPU part that is bound by its LINK (many similar streams: no stream dominates) gains from the host only what
     // the spare cores add to the link's rate, and those cores share memory bandwidth and the CPU quota with the fill threads
     // and the copy engine: measured on the GPU box, a modelled 5-8 % came out between +2 % and -7 %
     // (profiles/r04_default_probe.txt).  Such a batch is split only for a modelled 10 % or more.
-    if (best_k > 0 && best_k < n && suffix[0] / link >= (double)lens[order[0]] / m.gpu_pair_rate && best > 0.90 * gpu_time(0)) {
-        best = gpu_time(0);
+    if (best_k > 0 && best_k < n && suffix[0] / link >= (double)lens[order[0]] / m.gpu_pair_rate && best > 0.90 * gpu_alone) {
+        best = gpu_alone;
         best_k = 0;
         best_host = 0;
     }
     // no GPU part at all: the fill threads' cores hash too
-    unsigned threads = h_mixed;
-    if (h_alone > h_mixed) {
+    if (h_alone > threads || best_k == 0) {
+        const double hs = h_stream(h_alone);
         double work = 0;
-        for (size_t k = 0; k < n; ++k) work += host_cost(k);
-        if (std::max(work / h_alone, host_cost(0)) < best * 0.98) { // the lower bound first: the LPT pass is O(n log threads)
+        for (size_t k = 0; k < n; ++k) work += (double)lens[order[k]] / h_rate + hs;
+        if (std::max(work / h_alone, (double)lens[order[0]] / h_rate + hs) < best * 0.98) { // the lower bound first: the LPT pass is O(n log threads)
             MinHeap pool;
             for (unsigned t = 0; t < h_alone; ++t) pool.push(0.0);
             double mk = 0;
             for (size_t k = 0; k < n && mk < best; ++k) {
-                const double t = pool.top() + host_cost(k);
+                const double t = pool.top() + (double)lens[order[k]] / h_rate + hs;
                 pool.pop();
                 pool.push(t);
                 mk = std::max(mk, t);
@@ -103,10 +122,11 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
     }
 
     double work = 0;
+    const double hs_used = h_stream(threads);
     for (size_t k = 0; k < best_k; ++k) {
         res.on_host[order[k]] = 1;
         res.host_bytes += lens[order[k]];
-        work += host_cost(k);
+        work += (double)lens[order[k]] / h_rate + hs_used;
     }
     res.host_streams = best_k;
     res.gpu_seconds = gpu_time(best_k);

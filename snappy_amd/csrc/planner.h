@@ -26,7 +26,9 @@ struct PlanModel {
     double gpu_wide_rate = 18e6;  // B/s of ONE stream under the lane-per-stream kernel
     double gpu_link = 0;          // B/s one engine stages and copies (PCIe inclusive); 0 = 55e9 memory, 54e9 files (measured end to end, r04)
     double gpu_latency = 150e-6;  // s a launch costs whatever its size: job upload, kernel start, sync, digests back
-    double gpu_per_stream = 0;    // s per stream of planning + fill on the GPU side; 0 = 0.15 us memory, 0.5 us files
+    double gpu_per_stream = 0;    // s per stream of batch planning on the engine's thread; 0 = 0.15 us
+    double fill_rate = 0;         // B/s ONE fill thread moves into the staging buffers; 0 = 9e9 memory, 6.5e9 files (pread)
+    double fill_per_stream = 0;   // s per stream on a fill thread (files: open + close beside eleven others); 0 = 0.3 us memory, 10 us files
 };
 
 struct PlanResult {
@@ -37,6 +39,13 @@ struct PlanResult {
     uint64_t host_streams = 0, host_bytes = 0;
 };
 
+// The GPU part costs its launch latency + per-stream planning + the largest of: its longest stream at the kernel's
+// per-stream rate, its bytes over the link, its fill work over its fill threads.  The host part is LPT over its
+// threads.  With host_threads = 0 every host thread count from "what the fill threads and the engine leave" up to
+// "all cores but two" is tried, the fill threads keeping theirs (they work in bursts); beyond the cores' number what
+// binds is their total: (fill work + host work) / cpus.  A GPU part bound by its longest stream (a tree of many small
+// files and a few big ones) leaves cores to the big files; one bound by its link gives up the share the cores can hash
+// while they also feed it.
 // Streams move to the host longest first -- the longest sets the GPU's makespan and costs the host least per byte of
 // relief -- while that shortens max(GPU, host); and the whole batch moves when the host alone beats every split (a
 // batch too small to repay a launch, or one whose longest member is most of it).

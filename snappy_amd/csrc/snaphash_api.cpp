@@ -1737,6 +1737,7 @@ try {
     pm->host_streams = r.host_streams;
     pm->host_bytes = r.host_bytes;
     pm->host_threads_used = r.host_threads;
+    pm->reserved = 0;
     return SNAPHASH_OK;
 } catch (...) {
     return SNAPHASH_ENOMEM;

@@ -91,6 +91,36 @@ def test_explicit_thread_count_and_more_cores(built_lib):
     assert one["host_bytes"] < 0.05 * sum(lens)
 
 
+def test_many_small_files_and_a_few_big_ones_are_split_not_sent_to_the_host_whole(built_lib):
+    """BASELINE config 5 as an on-disk tree (100 000 Zipf files): the GPU part is bound by its longest stream, not by its
+    link, so it needs few cores and the big files get them -- 0.26 s on the GPU box, where sending every stream to the 16
+    host threads (what a per-file cost of 4 us made the planner believe in) took 0.31-0.34 (profiles/r04_c5_on_disk_tree.txt)."""
+    from snappy_amd import synthetic
+    lens = [int(x) for x in synthetic.config_sizes("C5")]
+    for from_files in (1, 0):
+        on_host, r = _plan(lens, from_files=from_files)
+        assert 10 <= r["host_streams"] <= 200 and r["host_bytes"] > 0.25 * sum(lens)  # the head and its like, nothing else
+        assert 3 <= r["host_threads"] <= 14 and r["gpu_seconds"] > 0
+        head = max(range(len(lens)), key=lambda i: lens[i])
+        assert on_host[head] == 1 and abs(r["host_seconds"] - lens[head] / 1.4e9) < 0.03  # the floor: the head on one core
+
+
+def test_a_link_bound_tree_gives_up_what_the_cores_can_hash_while_they_feed_it(built_lib):
+    """Config 2 from files: the fill threads keep their count (they work in bursts), host threads come on top, and the
+    cores' total binds: a seventh of the bytes at 16 cores (175 ms against 198 GPU-only, profiles/r04_default_probe.txt),
+    none at 8, most of them at 128."""
+    lens = [MiB] * 10001
+    _, r16 = _plan(lens, from_files=1, cpus=16)
+    assert 0.08 * sum(lens) < r16["host_bytes"] < 0.20 * sum(lens) and 4 <= r16["host_threads"] <= 10
+    assert r16["gpu_seconds"] < 0.9 * 10001 * MiB / 54e9
+    _, r8 = _plan(lens, from_files=1, cpus=8)
+    assert r8["host_bytes"] == 0
+    _, r128 = _plan(lens, from_files=1, cpus=128)
+    assert r128["host_bytes"] > 0.5 * sum(lens) and r128["host_threads"] > 64
+    # a rank's shard of it (1 250 x 1 MiB) is bound by its streams' own 24 ms: left alone
+    assert _plan([MiB] * 1250, from_files=1)[1]["host_streams"] == 0
+
+
 def test_plan_is_deterministic_and_covers_every_stream(built_lib):
     import random
     rng = random.Random(5)

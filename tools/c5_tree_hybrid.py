@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""BASELINE config 5 (100 000 Zipf files, 3.0 GiB) as a real on-disk tree (tmpfs) -> hashes.yaml, GPU only and with
-hybrid scheduling: where does the time go once the 256 MiB head file no longer sets it?  usage: tools/c5_tree_hybrid.py"""
+"""BASELINE config 5 (100 000 Zipf files, 3.0 GiB) as a real on-disk tree (tmpfs) -> hashes.yaml, GPU only and as
+planned (ABI 4): where does the time go once the 256 MiB head file no longer sets it?  usage: tools/c5_tree_hybrid.py"""
 import os
 import shutil
 import sys
@@ -39,10 +39,12 @@ try:
     host[int(off[n]):int(off[n]) + int(sizes[n])].tofile(tar)
     print("tree of %d files, %.2f GiB, written in %.1f s" % (n + 1, total / 2**30, time.perf_counter() - t0), flush=True)
     ref = None
-    for ht in (0, 4, 16):
-        with Context(host_threads=ht) as c:
+    from snappy_amd import _lib
+    for name, kw, reps in (("GPU only", dict(flags=_lib.FLAG_GPU_ONLY), 1), ("default (planned)", dict(flags=0), 5), ("host_threads=4", dict(flags=0, host_threads=4), 3)) + tuple(
+            ("host_threads=%d" % int(a), dict(flags=0, host_threads=int(a)), 3) for a in sys.argv[1:]):
+        with Context(**kw) as c:
             best = None
-            for rep in range(3 if ht else 1):
+            for rep in range(reps):
                 t0 = time.perf_counter()
                 y = c.tree(build, tar)
                 dt = time.perf_counter() - t0
@@ -50,11 +52,11 @@ try:
                     best = (dt, c.stats(), c.stats_ex())
             dt, st, ex = best
             ref = ref or y
-            print("host_threads=%2d: %.3f s = %.2f GiB/s  (kernels %.0f ms, h2d %.0f ms, host streams %d / %.0f MiB, yaml %s)" % (
-                ht, dt, total / 2**30 / dt, st["kernel_ms"], st["h2d_ms"], ex["host_streams"], ex["host_bytes"] / 2**20,
+            print("%-18s %.3f s = %.2f GiB/s  (kernels %.0f ms, h2d %.0f ms, host streams %d / %.0f MiB, yaml %s)" % (
+                name + ":", dt, total / 2**30 / dt, st["kernel_ms"], st["h2d_ms"], ex["host_streams"], ex["host_bytes"] / 2**20,
                 "identical" if y == ref else "DIFFERS"), flush=True)
             t0 = time.perf_counter()
             assert c.verify(build, y, tar) is None
-            print("                 verify %.3f s" % (time.perf_counter() - t0), flush=True)
+            print("                   verify %.3f s" % (time.perf_counter() - t0), flush=True)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)

@@ -317,25 +317,19 @@ bool unhex64(const std::string& s, uint8_t out[64])
 
 } // namespace
 
-int parse_yaml(const char* text, size_t len, ParsedHashes& out)
+namespace {
+
+// lines [lo, hi) of a hashes.yaml; in_files_at_start: the range begins inside the `files:` list (at an item's first
+// line).  *top_level (may be NULL) is set when a top-level key is met -- a range parsed on its own must not meet one.
+int parse_lines(const std::vector<std::string_view>& lines, size_t lo, size_t hi, bool in_files_at_start, ParsedHashes& out, bool* top_level)
 {
-    out = ParsedHashes();
-    std::vector<std::string_view> lines; // views into the caller's text: a line is copied only when it is worked on
-    {
-        size_t i = 0;
-        while (i < len) {
-            size_t j = i;
-            while (j < len && text[j] != '\n') ++j;
-            lines.emplace_back(text + i, j - i);
-            i = j + 1;
-        }
-    }
-    bool in_files = false;
+    bool in_files = in_files_at_start;
     int skip_indent = -1; // inside a nested block we ignore (xattr)
     ParsedRecord* cur = nullptr;
     auto indent_of = [](std::string_view l) { size_t k = 0; while (k < l.size() && l[k] == ' ') ++k; return k; };
     std::string line;
-    for (size_t li = 0; li < lines.size(); ++li) {
+    std::string key, val, sv; // (outside the loop: their capacity is kept from line to line)
+    for (size_t li = lo; li < hi; ++li) {
         line.assign(lines[li].data(), lines[li].size());
         while (!line.empty() && (line.back() == '\r')) line.pop_back();
         size_t ind = 0;
@@ -343,11 +337,11 @@ int parse_yaml(const char* text, size_t len, ParsedHashes& out)
         // A scalar the emitter folded (yaml.v2 breaks lines past column 80 at a space, yamlscalar.cpp): the lines that
         // follow a "key: value" of a list item and are indented deeper than the item's keys continue the value; the
         // break and the indentation stand for one space.
-        if (in_files && skip_indent < 0 && ind < line.size() && line[ind] != '#') {
+        if (in_files && (skip_indent < 0 || (int)ind <= skip_indent) && ind < line.size() && line[ind] != '#') { // (a line that ends a skipped block is worked on)
             const size_t key_col = line[ind] == '-' ? ind + 2 : ind;
             const size_t colon = line.find(": ", ind);
             if (colon != std::string::npos && colon + 2 < line.size()) {
-                while (li + 1 < lines.size()) {
+                while (li + 1 < hi) {
                     std::string_view nx = lines[li + 1];
                     while (!nx.empty() && (nx.back() == '\r' || nx.back() == ' ')) nx.remove_suffix(1);
                     const size_t ni = indent_of(nx);
@@ -365,8 +359,8 @@ int parse_yaml(const char* text, size_t len, ParsedHashes& out)
             if ((int)ind > skip_indent) continue;
             skip_indent = -1;
         }
-        std::string key, val, sv;
         if (ind == 0 && line[0] != '-') { // top-level key
+            if (top_level) *top_level = true;
             if (line == "{}") continue;   // common_test.go:77-80: an empty document is acceptable
             if (!split_key(line, 0, key, val)) return SNAPHASH_EPARSE;
             in_files = false;
@@ -413,6 +407,79 @@ int parse_yaml(const char* text, size_t len, ParsedHashes& out)
             cur->has_mode = true;
         }
         // unknown keys are ignored, as yaml.v2 does for non-strict Unmarshal
+    }
+    return SNAPHASH_OK;
+}
+
+} // namespace
+
+int parse_yaml(const char* text, size_t len, ParsedHashes& out)
+{
+    out = ParsedHashes();
+    std::vector<std::string_view> lines; // views into the caller's text: a line is copied only when it is worked on
+    {
+        size_t i = 0;
+        while (i < len) {
+            const char* nl = (const char*)memchr(text + i, '\n', len - i);
+            const size_t j = nl ? (size_t)(nl - text) : len;
+            lines.emplace_back(text + i, j - i);
+            i = j + 1;
+        }
+    }
+    // A big document (100 000 files: 20 MB, 400 000 lines) is parsed in ranges that begin at an item of the `files:` list,
+    // each by a thread of its own: an item's lines depend on nothing before them.  The head up to `files:` first; a
+    // range that meets anything but list items (a further top-level key) sends the whole text down the serial way.
+    const unsigned T = (unsigned)std::min<size_t>(std::min(8u, usable_cpus()), lines.size() / 20000);
+    size_t f_line = lines.size();
+    if (T > 1)
+        for (size_t i = 0; i < lines.size(); ++i) {
+            std::string_view l = lines[i];
+            while (!l.empty() && (l.back() == '\r' || l.back() == ' ')) l.remove_suffix(1);
+            if (l == "files:") { f_line = i; break; }
+            if (!l.empty() && l[0] == '-') break; // an item before any `files:`: not the shape this shortcut is for
+        }
+    bool done = false;
+    if (T > 1 && f_line + 1 < lines.size()) {
+        ParsedHashes head;
+        int rc = parse_lines(lines, 0, f_line + 1, false, head, nullptr);
+        if (rc == SNAPHASH_OK) {
+            std::vector<size_t> cut(T + 1, lines.size());
+            cut[0] = f_line + 1;
+            for (unsigned t = 1; t < T; ++t) {
+                size_t at = f_line + 1 + (lines.size() - f_line - 1) * t / T;
+                while (at < lines.size() && !(lines[at].size() >= 2 && lines[at][0] == '-' && lines[at][1] == ' ')) ++at;
+                cut[t] = std::max(at, cut[t - 1]);
+            }
+            std::vector<ParsedHashes> part(T);
+            std::vector<int> prc(T, SNAPHASH_OK);
+            std::vector<char> top(T, 0);
+            {
+                ThreadJoiner th;
+                auto work = [&](unsigned t) {
+                    bool tl = false;
+                    prc[t] = cut[t] < cut[t + 1] ? parse_lines(lines, cut[t], cut[t + 1], true, part[t], &tl) : SNAPHASH_OK;
+                    top[t] = tl;
+                };
+                for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work, t);
+                work(0);
+            }
+            bool clean = true;
+            for (unsigned t = 0; t < T; ++t) clean = clean && prc[t] == SNAPHASH_OK && !top[t];
+            if (clean) {
+                out = std::move(head);
+                size_t total = out.files.size();
+                for (unsigned t = 0; t < T; ++t) total += part[t].files.size();
+                out.files.reserve(total);
+                for (unsigned t = 0; t < T; ++t)
+                    for (ParsedRecord& r : part[t].files) out.files.push_back(std::move(r));
+                done = true;
+            }
+        }
+    }
+    if (!done) {
+        out = ParsedHashes();
+        const int rc = parse_lines(lines, 0, lines.size(), false, out, nullptr);
+        if (rc != SNAPHASH_OK) return rc;
     }
     for (const ParsedRecord& r : out.files)
         if (!r.has_name || !r.has_mode) return SNAPHASH_EPARSE;

@@ -248,6 +248,66 @@ def test_parse_yaml_reader_side(built_lib):
         assert e.value.code == _lib.EPARSE, bad
 
 
+def test_a_big_hashes_yaml_is_parsed_in_ranges_and_comes_out_the_same(built_lib):
+    """hostpass.cpp parse_yaml: a document of 20 000 lines and more is parsed in ranges that begin at a list item, a thread
+    each.  Names that are quoted, folded over several lines, or look like list items inside their continuation lines sit
+    where the cuts fall; a further top-level key after the list, or a broken line, sends the text down the serial way."""
+    import random
+    from snappy_amd import _lib, SnaphashError
+    rng = random.Random(12)
+    want, lines = [], ["archive-sha512: " + "ab" * 64, "files:"]
+    for i in range(15000):
+        kind = rng.randrange(12)
+        if kind == 0:
+            name = "d%05d/" % i + " ".join("word%d" % rng.randrange(1000) for _ in range(30))  # folded by the emitter past column 80
+            folded = ["- name: " + name[:60].rsplit(" ", 1)[0]]
+            rest = name[len(folded[0]) - 8 + 1:]
+            while rest:
+                cut = rest[:70].rsplit(" ", 1)[0] if len(rest) > 70 and " " in rest[:70] else rest
+                folded.append("    " + cut)
+                rest = rest[len(cut) + 1:]
+            lines += folded
+        elif kind == 1:
+            name = "d%05d/it's - name: not an item" % i
+            lines.append("- name: '" + name.replace("'", "''") + "'")
+        elif kind == 2:
+            name = "d%05d/tab\there" % i
+            lines.append('- name: "d%05d/tab\\there"' % i)
+        else:
+            name = "d%05d/f%07d.bin" % (i // 100, i)
+            lines.append("- name: " + name)
+        if kind == 3:
+            want.append((name, None, "drwxr-xr-x"))
+            lines.append("  mode: drwxr-xr-x")
+        else:
+            size = rng.randrange(1 << 40)
+            hexd = "%0128x" % rng.getrandbits(512)
+            want.append((name, (size, hexd), "frw-r--r--"))
+            lines += ["  size: %d" % size, "  sha512: " + hexd, "  mode: frw-r--r--"]
+            if kind == 4:
+                lines += ["  xattr:", "    user.k: v", "    - name: inside a nested block"]
+    text = ("\n".join(lines) + "\n").encode()
+    assert len(lines) > 40000
+
+    def check(t):
+        arch, recs = _lib.parse_yaml(t)
+        assert arch == "ab" * 64 and len(recs) == len(want)
+        for r, (name, fs, mode) in zip(recs, want):
+            assert r["name"] == name, (r["name"], name)
+            assert _lib.mode_string(r["st_mode"]) == mode
+            if fs:
+                assert (r["size"], r["sha512"]) == fs
+    check(text)
+    check(text.replace(b"\n", b"\r\n"))
+    check(text + b"later-key: 1\n")                          # not only list items after `files:`: the serial way, same records
+    check(b"# a comment\n---\n" + text)
+    broken = text.replace(b"  mode: frw-r--r--\n- name: d00120", b"  mode: ?rw-r--r--\n- name: d00120", 1)
+    assert broken != text
+    with pytest.raises(SnaphashError) as e:
+        _lib.parse_yaml(broken)
+    assert e.value.code == _lib.EPARSE
+
+
 def test_hostpass_under_asan_and_ubsan(tmp_path):
     """hostpass.cpp (walk, emitter, parser of untrusted hashes.yaml, LPT) built with
     -fsanitize=address,undefined and driven with 20 000 mutated documents."""
@@ -283,7 +343,7 @@ def test_threaded_host_code_under_tsan(tmp_path):
         for e in range(3):
             p = build / ("d%02d" % d) / ("e%d" % e)
             p.mkdir(parents=True)
-            for f in range(40):
+            for f in range(90):  # 10 800 files: their hashes.yaml is long enough for the parser's ranges too
                 (p / ("f%03d" % f)).write_bytes(b"x" * (f * 13))
     big = tmp_path / "big.bin"
     big.write_bytes(os.urandom(1 << 20) * 40)

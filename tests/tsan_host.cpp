@@ -1,6 +1,6 @@
 // Test-only driver: the library's multi-threaded HOST code under ThreadSanitizer (CPU build; GPU sanitizers are not
 // available on the pool).  What runs on more than one thread beside the kernels: the level-wise parallel walk
-// (walk.cpp), the ranged YAML emitter (hostpass.cpp), the persistent pool of staging-fill threads (hostfill.cpp
+// (walk.cpp), the ranged YAML emitter and parser (hostpass.cpp), the persistent pool of staging-fill threads (hostfill.cpp
 // FillPool), the read-ahead reader of one long host-hashed file (hostsha.cpp) and the thread sets of a planned host
 // part (ThreadJoiner).  Exit code 0 = no report, every result equal to the single-threaded one.
 //
@@ -36,7 +36,7 @@ int main(int argc, char** argv)
         if (round == 0) {
             first = recs;
             first_yaml = y;
-            ParsedHashes ph;
+            ParsedHashes ph; // (40 000 lines and more: parsed in ranges, a thread each)
             if (parse_yaml(y.data(), y.size(), ph) != SNAPHASH_OK || ph.files.size() != recs.size()) return 6;
             for (size_t i = 0; i < recs.size(); ++i)
                 if (ph.files[i].name != recs[i].name) return 7;

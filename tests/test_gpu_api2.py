@@ -341,9 +341,11 @@ def test_default_configuration_plans_every_call(built_lib, oracle, tmp_path):
         t0 = time.perf_counter()
         got = c.sha512_files(paths)
         t_small = time.perf_counter() - t0
-        assert c.stats_ex()["gpu_bytes"] == 0 and c.stats()["launches"] == 0
+        cores = _lib.lib().snaphash_usable_cpus()
+        if cores >= 4:  # (one core alone needs 40 ms for these: there the kernels' 24 ms win, and the planner says so)
+            assert c.stats_ex()["gpu_bytes"] == 0 and c.stats()["launches"] == 0
         assert got == [oracle.sha512(open(p, "rb").read()) for p in paths]
-        assert t_small < 0.0235  # GPU only: 23.8 ms for the 1 MiB members alone (16 cores: ~3 ms)
+        assert t_small < (0.0235 if cores >= 4 else 0.05)  # GPU only: 23.8 ms for the 1 MiB members alone (16 cores: ~3 ms)
         # the literal helpers.Sha512sum call: one file, the calling thread, no launch
         t0 = time.perf_counter()
         assert c.sha512_buffers([b"x"]) == [hashlib.sha512(b"x").digest()]

@@ -1,6 +1,8 @@
 // hostfill.cpp -- see hostfill.h.
 #include "hostfill.h"
 
+#include <new>
+
 #include <ctype.h>
 #include <dirent.h>
 #include <errno.h>
@@ -260,10 +262,14 @@ void FillPool::worker(unsigned id)
             seen = epoch_;
             fn = fn_; n = n_; next = next_;
         }
-        for (;;) {
-            const size_t i = next->fetch_add(1);
-            if (i >= n) break;
-            (*fn)(i);
+        try {
+            for (;;) {
+                const size_t i = next->fetch_add(1);
+                if (i >= n) break;
+                (*fn)(i);
+            }
+        } catch (...) { // (not on the caller's stack: remembered, raised there)
+            fn_threw_.store(true);
         }
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -293,10 +299,16 @@ void FillPool::parallel_for(size_t n, unsigned threads, const std::function<void
         }
     }
     if (helpers) cv_work_.notify_all();
-    for (;;) {
-        const size_t i = next.fetch_add(1);
-        if (i >= n) break;
-        fn(i);
+    bool threw = false;
+    try {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n) break;
+            fn(i);
+        }
+    } catch (...) { // the helpers still hold fn and next, which live on this stack: stop them, wait, then raise
+        threw = true;
+        next.store(n);
     }
     if (helpers) {
         std::unique_lock<std::mutex> lk(mu_);
@@ -304,6 +316,7 @@ void FillPool::parallel_for(size_t n, unsigned threads, const std::function<void
         want_ = 0;
         fn_ = nullptr; next_ = nullptr;
     }
+    if (fn_threw_.exchange(false) || threw) throw std::bad_alloc();
 }
 
 // ---- copy_to_staging ------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -52,16 +53,31 @@ unsigned cgroup_cpu_quota(const std::string& sysfs_cgroup_root, const std::strin
 // Threads that are joined whatever path leaves the scope.  A std::thread constructor that throws (EAGAIN) halfway
 // through a pool would otherwise destroy joinable threads: std::terminate, which no catch at the C boundary can stop
 // (ADVICE r3).  The workers must end by themselves (they run to completion or watch a flag the owner sets).
+// An exception INSIDE a worker (an allocation that fails while a directory is listed, a record written) would end the
+// process the same way -- no catch at the C boundary is on that thread's stack: spawn() runs the worker under a catch,
+// remembers that it threw, and join_all() raises std::bad_alloc on the owner's thread, where the entry point's catch is.
 struct ThreadJoiner {
     std::vector<std::thread> th;
+    std::atomic<bool> worker_threw{false};
     ThreadJoiner() = default;
     ThreadJoiner(const ThreadJoiner&) = delete;
     ThreadJoiner& operator=(const ThreadJoiner&) = delete;
-    ~ThreadJoiner() { join_all(); }
-    void join_all()
+    ~ThreadJoiner() { join_quietly(); }
+    template <class F, class... A> void spawn(F&& f, A&&... a)
+    {
+        th.emplace_back([this](auto fn, auto... args) {
+            try { fn(args...); } catch (...) { worker_threw.store(true); }
+        }, std::forward<F>(f), std::forward<A>(a)...);
+    }
+    void join_quietly()
     {
         for (auto& t : th)
             if (t.joinable()) t.join();
+    }
+    void join_all()
+    {
+        join_quietly();
+        if (worker_threw.exchange(false)) throw std::bad_alloc();
     }
 };
 
@@ -93,6 +109,7 @@ private:
     unsigned running_ = 0;     // pool threads still inside the current job
     bool quit_ = false;
     const std::function<void(size_t)>* fn_ = nullptr;
+    std::atomic<bool> fn_threw_{false}; // a pool thread's fn(i) threw: parallel_for raises std::bad_alloc on the caller's thread
     size_t n_ = 0;
     std::atomic<size_t>* next_ = nullptr;
 };

@@ -200,7 +200,7 @@ int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64],
     };
     {
         ThreadJoiner th;
-        for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work, t);
+        for (unsigned t = 1; t < T; ++t) th.spawn(work, t);
         work(0);
         th.join_all();
     }
@@ -460,7 +460,7 @@ int parse_yaml(const char* text, size_t len, ParsedHashes& out)
                     prc[t] = cut[t] < cut[t + 1] ? parse_lines(lines, cut[t], cut[t + 1], true, part[t], &tl) : SNAPHASH_OK;
                     top[t] = tl;
                 };
-                for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work, t);
+                for (unsigned t = 1; t < T; ++t) th.spawn(work, t);
                 work(0);
             }
             bool clean = true;

@@ -980,9 +980,9 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     const bool gpu_part = !gidx.empty();
     ThreadJoiner th, dth;
     try {
-        for (unsigned t = gpu_part ? 0u : 1u; t < nh; ++t) th.th.emplace_back(run_host, t);
+        for (unsigned t = gpu_part ? 0u : 1u; t < nh; ++t) th.spawn(run_host, t);
         if (gpu_part && nd > 1)
-            for (size_t d = 0; d < nd; ++d) dth.th.emplace_back(run_dev, d);
+            for (size_t d = 0; d < nd; ++d) dth.spawn(run_dev, d);
     } catch (...) { // no thread to be had: end what runs (the joiners wait for it), report, hash nothing further
         int z = 0;
         herr.compare_exchange_strong(z, EAGAIN);
@@ -1082,7 +1082,7 @@ int hash_paths(snaphash_ctx* x, const char* const* paths, size_t n, const int64_
             }
         };
         ThreadJoiner th; // (an emplace_back that throws leaves through the entry point's catch; what was started is joined)
-        for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work, t);
+        for (unsigned t = 1; t < T; ++t) th.spawn(work, t);
         work(0);
         th.join_all();
         int64_t first = -1;
@@ -2219,7 +2219,7 @@ try {
             p.rc = files_equal_impl(c, p.a.data(), p.b.data(), p.idx.size(), p.eq.data());
         };
         ThreadJoiner th;
-        for (size_t d = 1; d < nd; ++d) th.th.emplace_back(run, d);
+        for (size_t d = 1; d < nd; ++d) th.spawn(run, d);
         run(0);
         th.join_all();
         for (size_t d = 0; d < nd; ++d) {

@@ -80,7 +80,7 @@ void list_tree(const std::string& root, std::vector<DirList>& dirs)
         };
         {
             ThreadJoiner th;
-            for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work);
+            for (unsigned t = 1; t < T; ++t) th.spawn(work);
             work();
             th.join_all();
         }
@@ -187,7 +187,7 @@ int walk_entries(const char* root_c, std::vector<WalkEntry>& ents, int* err_no, 
     };
     {
         ThreadJoiner th; // joined even when a thread cannot be started (the exception then leaves through the C entry point's catch)
-        for (unsigned t = 1; t < T; ++t) th.th.emplace_back(work, t);
+        for (unsigned t = 1; t < T; ++t) th.spawn(work, t);
         work(0);
         th.join_all();
     }

@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <functional>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -103,6 +105,36 @@ int main(int argc, char** argv)
         HostSha s3;
         host_sha512_init(s3);
         if (host_sha512_file_from(s3, argv[2], 0, len + 4096, a, true) == 0) return 19;
+    }
+    // 4. a worker that throws (an allocation failing inside a thread): contained there, raised on the owner's thread, and
+    //    the pool goes on working
+    {
+        bool raised = false;
+        try {
+            ThreadJoiner tj;
+            tj.spawn([](int k) { if (k == 1) throw std::bad_alloc(); }, 1);
+            tj.spawn([](int) {}, 0);
+            tj.join_all();
+        } catch (const std::bad_alloc&) {
+            raised = true;
+        }
+        if (!raised) return 20;
+        FillPool pool;
+        pool.configure(4, {});
+        for (int where = 0; where < 2; ++where) { // thrown on a pool thread (some item far from the caller's first), then on any
+            raised = false;
+            std::atomic<size_t> done{0};
+            const std::function<void(size_t)> fn = [&](size_t i) {
+                if (where == 0 ? i == 777 : i % 97 == 5) throw std::bad_alloc();
+                done.fetch_add(1, std::memory_order_relaxed);
+            };
+            try { pool.parallel_for(2000, 4, fn); } catch (const std::bad_alloc&) { raised = true; }
+            if (!raised) return 21;
+        }
+        std::atomic<size_t> ok{0};
+        const std::function<void(size_t)> fine = [&](size_t) { ok.fetch_add(1, std::memory_order_relaxed); };
+        pool.parallel_for(3000, 4, fine);
+        if (ok.load() != 3000) return 22;
     }
     printf("tsan driver ok\n");
     return 0;

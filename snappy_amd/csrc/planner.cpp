@@ -36,8 +36,9 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
     const unsigned fill = std::max(1u, m.fill_threads) * nd;
     const unsigned h_base = cpus > fill + 1u ? cpus - fill - 1u : 1u; // beside a GPU part at full fill: its fill threads and the engine's own thread keep their cores
     const unsigned h_alone = m.host_threads ? m.host_threads : cpus;   // no GPU part: every core hashes
-    // a stream's fixed cost on a host thread: for files open + fstat + close, which do not scale (the threads meet on the
-    // directories' reference counts): 4 us alone, ~20 us each with sixteen at it (100 000 files, profiles/r04_c5_on_disk_tree.txt)
+    // a stream's fixed cost on a host thread: for files open + close, which do not scale -- every thread of a process takes
+    // the lock of its ONE descriptor table (openat relative to the directory's descriptor changes nothing, lstat scales
+    // fine: profiles/r04_openat_probe.txt): 3 us alone, 19 us each with twelve at it, 25 with sixteen (100 000 files)
     auto h_stream = [&](unsigned threads) {
         if (m.host_per_stream > 0) return m.host_per_stream;
         return m.from_files ? 4e-6 * std::max(1.0, (double)threads / 3.0) : 0.05e-6;

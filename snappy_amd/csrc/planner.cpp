@@ -13,6 +13,7 @@ namespace {
 // into a long head for it and a short tail for the lane-per-stream kernel)
 constexpr size_t kPairMaxStreams = 32768;
 constexpr uint64_t kPairMinBlocks = 32;
+constexpr uint64_t kMinHostFile = 256u << 10; // a file smaller than this does not move to a host thread while there is a GPU part (below)
 constexpr double kThreadWorth = 250e-6; // a further host thread is started per this much host work (a start costs ~30 us)
 
 uint64_t blocks_of(uint64_t len) { return (len >> 7) + 1; }
@@ -81,6 +82,10 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
         for (unsigned t = 0; t < h; ++t) pool.push(0.0);
         double host_makespan = 0, host_work = 0;
         for (size_t k = 0; k < n; ++k) {
+            // A small file costs its open + close more than its bytes, and that cost is the same lock whoever pays it (the
+            // process has one descriptor table): beside a GPU part it stays with the fill threads -- 100 000 x 8 KiB took
+            // 148 ms with a quarter of them on host threads against 115 ms whole (profiles/r04_small_files_tree.txt).
+            if (m.from_files && lens[order[k]] < kMinHostFile) break;
             const double c = (double)lens[order[k]] / h_rate + hs;
             const double t = pool.top() + c;
             pool.pop();
@@ -104,7 +109,7 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
         best_host = 0;
     }
     // no GPU part at all: the fill threads' cores hash too
-    if (h_alone > threads || best_k == 0) {
+    if (best_k < n || h_alone > threads) {
         const double hs = h_stream(h_alone);
         double work = 0;
         for (size_t k = 0; k < n; ++k) work += (double)lens[order[k]] / h_rate + hs;

@@ -121,6 +121,25 @@ def test_a_link_bound_tree_gives_up_what_the_cores_can_hash_while_they_feed_it(b
     assert _plan([MiB] * 1250, from_files=1)[1]["host_streams"] == 0
 
 
+def test_small_files_stay_with_the_gpu_part(built_lib):
+    """A small file costs its open + close more than its bytes, and that is one lock per process whoever pays it
+    (profiles/r04_openat_probe.txt): beside a GPU part it does not move to a host thread -- 100 000 x 8 KiB took 148 ms with a
+    quarter of them on host threads, 115 ms whole (profiles/r04_small_files_tree.txt).  From memory there is no such cost."""
+    for lens in ([8192] * 100000, [65536] * 50000, [8192] * 5000):
+        on_host, r = _plan(lens, from_files=1)
+        assert r["host_streams"] == 0 and r["gpu_seconds"] > 0, (len(lens), r)
+    _, r = _plan([100 << 10] * 20000, from_files=0)
+    assert r["host_streams"] > 0
+    # the big members of such a tree still move, and nothing below 256 KiB with them
+    lens = [8192] * 20000 + [8 * MiB] * 6 + [200 << 10] * 50
+    on_host, r = _plan(lens, from_files=1)
+    assert all(on_host[i] == 0 for i in range(len(lens)) if lens[i] < (256 << 10))
+    assert sum(on_host) >= 1 and all(lens[i] == 8 * MiB for i in range(len(lens)) if on_host[i])
+    # and a batch with no GPU part left at all (a few dozen members) still goes to the host whole
+    on_host, r = _plan(BREAKEVEN["24 files incl. one 1 MiB"], from_files=1)
+    assert sum(on_host) == 24 and r["gpu_seconds"] == 0
+
+
 def test_plan_is_deterministic_and_covers_every_stream(built_lib):
     import random
     rng = random.Random(5)

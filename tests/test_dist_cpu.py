@@ -94,7 +94,7 @@ def _tree_worker(rank, world, port, build, tar, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_tree_plan_gather_emit_gloo(world, oracle, built_lib, tmp_path):
     """ABI 4 snaphash_shard_plan / _emit (host-only halves of the one-process-per-GPU pass): every rank walks the tree,
     takes its LPT share, the slabs are all-gathered over gloo, and EVERY rank writes the oracle's hashes.yaml."""

@@ -951,26 +951,39 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     const bool spare_cores = 2u * nh <= x->cpus; // a long file stream may take a reader thread beside its hasher (hostsha.h)
     std::vector<double> hbusy(std::max(1u, nh), 0.0);
     std::stable_sort(hidx.begin(), hidx.end(), [&](uint32_t a, uint32_t b) { return src[a].len > src[b].len; });
+    // A thread takes streams off the queue (longest first) and runs up to eight of them side by side, a stream per 64-bit
+    // lane (hostsha_x8.cpp: ~3x a core's one-stream rate) -- but a stream that is a quarter of a thread's share or more
+    // keeps a core to itself: it sets the makespan, and lanes share the core (config 5's 255 MiB head).
+    uint64_t host_bytes_planned = 0;
+    for (uint32_t g : hidx) host_bytes_planned += src[g].len;
+    const uint64_t alone_from = nh ? host_bytes_planned / nh / 4 : 0;
+    size_t n_lane_streams = 0;
+    for (uint32_t g : hidx) n_lane_streams += src[g].len < alone_from || alone_from == 0;
+    const unsigned host_lanes = nh ? (unsigned)std::min<size_t>(8, (n_lane_streams + nh - 1) / nh) : 1u;
     auto run_host = [&](unsigned t) {
         const double t0 = now_ms();
-        for (;;) {
-            const size_t k = hnext.fetch_add(1);
-            if (k >= hidx.size() || herr.load()) break;
-            const uint32_t g = hidx[k];
-            HostSha hs;
-            host_sha512_init(hs);
-            int err = 0;
-            if (src[g].mem) {
-                host_sha512_update(hs, src[g].mem, src[g].len);
-                host_sha512_final(hs, digests + 64 * (size_t)g);
-            } else {
-                err = host_sha512_file_from(hs, src[g].path, 0, src[g].len, digests + 64 * (size_t)g, spare_cores);
-            }
-            if (err) {
-                int z = 0;
-                if (herr.compare_exchange_strong(z, err)) herr_src.store(g);
-                break;
-            }
+        int64_t bad = -1;
+        const int err = host_sha512_many(
+            host_lanes,
+            [&]() -> int64_t {
+                if (herr.load()) return -1;
+                const size_t k = hnext.fetch_add(1);
+                return k < hidx.size() ? (int64_t)hidx[k] : -1;
+            },
+            [&](int64_t g) {
+                HostStream h;
+                h.mem = src[g].mem;
+                h.path = src[g].mem ? nullptr : src[g].path;
+                h.len = src[g].len;
+                h.digest = digests + 64 * (size_t)g;
+                h.read_ahead = spare_cores;
+                h.alone = alone_from != 0 && src[g].len >= alone_from;
+                return h;
+            },
+            &bad);
+        if (err) {
+            int z = 0;
+            if (herr.compare_exchange_strong(z, err)) herr_src.store(bad);
         }
         hbusy[t] = now_ms() - t0;
     };

@@ -87,3 +87,27 @@ extern "C" int hostsha_file(const char* path, uint64_t expect, uint8_t* out)
     host_sha512_init(a);
     return host_sha512_file_from(a, path, 0, expect, out, true);
 }
+
+// ---- eight streams side by side on one core (hostsha_x8.cpp), as a thread of the host pool runs them --------------
+#include "../snappy_amd/csrc/hostsha_x8.cpp"
+
+extern "C" int hostsha_x8_available() { return host_sha512_x8_available() ? 1 : 0; }
+// streams i with ptrs[i] != NULL are memory, the others files (paths[i]); alone_from: streams at least that long keep the
+// core to themselves (0 = none); -> 0 or an errno, *err_id = the failing stream
+extern "C" int hostsha_many(const uint8_t* const* ptrs, const char* const* paths, const uint64_t* lens, uint64_t n, unsigned lanes,
+                            uint64_t alone_from, uint8_t* digests, int64_t* err_id)
+{
+    uint64_t nexti = 0;
+    return host_sha512_many(
+        lanes, [&]() -> int64_t { return nexti < n ? (int64_t)nexti++ : -1; },
+        [&](int64_t id) {
+            HostStream h;
+            h.mem = ptrs[id];
+            h.path = ptrs[id] ? nullptr : paths[id];
+            h.len = lens[id];
+            h.digest = digests + 64 * id;
+            h.alone = alone_from != 0 && lens[id] >= alone_from;
+            return h;
+        },
+        err_id);
+}

@@ -97,3 +97,66 @@ def test_host_sha512_of_the_hybrid_scheduler(core, tmp_path_factory):
         assert L.hostsha_file(str(big).encode(), len(data), out) == 0 and out.raw == hashlib.sha512(data).digest()
     assert L.hostsha_file(str(big).encode(), len(data) - 1, out) == errno.EIO
     assert L.hostsha_file(str(big).encode(), len(data) + (1 << 20), out) == errno.EIO
+
+
+def test_eight_streams_side_by_side_on_one_core(core, tmp_path_factory):
+    """snappy_amd/csrc/hostsha_x8.cpp: a thread of the host pool runs up to eight streams at once, a stream per 64-bit lane
+    (AVX-512; one at a time elsewhere).  Memory and files mixed, every length class around the block and the 256 KiB chunk,
+    lanes that empty and refill at different times, 1..8 lanes, streams that keep the core to themselves -- every digest
+    hashlib's; a file that shrank, grew or is not there fails the call with its errno and its index."""
+    import errno
+    import hashlib
+    import random
+    import numpy as np
+    so = str(tmp_path_factory.mktemp("core8") / "libcorehost.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "core_host_harness.cpp"), "-pthread"])
+    L = ctypes.CDLL(so)
+    L.hostsha_many.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64,
+                               ctypes.c_uint, ctypes.c_uint64, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
+    rng = random.Random(31)
+    blob = np.random.default_rng(31).integers(0, 256, size=3 << 20, dtype=np.uint8).tobytes()
+    d = tmp_path_factory.mktemp("x8files")
+    classes = [0, 1, 111, 112, 127, 128, 129, 255, 256, 4095, 65536, (256 << 10) - 1, 256 << 10, (256 << 10) + 1, (256 << 10) + 128, (512 << 10) + 77, 1 << 20]
+
+    serial = [0]
+
+    def run(specs, lanes, alone_from=0):
+        n = len(specs)
+        ptrs, paths, lens, keep = (ctypes.c_char_p * n)(), (ctypes.c_char_p * n)(), (ctypes.c_uint64 * n)(), []
+        for i, (kind, data, claimed) in enumerate(specs):
+            lens[i] = len(data) if claimed is None else claimed
+            if kind == "mem":
+                keep.append(ctypes.create_string_buffer(data, max(len(data), 1)))
+                ptrs[i] = ctypes.cast(keep[-1], ctypes.c_char_p)
+            else:
+                serial[0] += 1
+                p = d / ("f%d" % serial[0])
+                keep.append(p)
+                if kind != "missing":
+                    p.write_bytes(data)
+                paths[i] = str(p).encode()
+        out = ctypes.create_string_buffer(64 * n)
+        bad = ctypes.c_int64(-7)
+        rc = L.hostsha_many(ptrs, paths, lens, n, lanes, alone_from, out, ctypes.byref(bad))
+        return rc, bad.value, [out.raw[64 * i:64 * i + 64] for i in range(n)]
+
+    for trial in range(60):
+        n = rng.randrange(1, 24)
+        specs = []
+        for i in range(n):
+            size = rng.choice(classes) if rng.random() < 0.6 else rng.randrange(0, 700000)
+            off = rng.randrange(0, len(blob) - size)
+            specs.append((rng.choice(["mem", "file"]), blob[off:off + size], None))
+        if trial % 3 == 0:
+            specs.sort(key=lambda s: -len(s[1]))  # longest first, as the pool hands them out
+        rc, bad, digs = run(specs, rng.randrange(1, 9), alone_from=(300000 if trial % 3 == 0 else 0))
+        assert rc == 0 and bad == -1
+        assert digs == [hashlib.sha512(s[1]).digest() for s in specs], trial
+    # the reference's io.Copy reads what is there: a size taken earlier that no longer holds is an error, whichever lane
+    base = [("file", blob[:70000], None)] * 5
+    for wrong, code in ((("file", blob[:50000], 50001), errno.EIO), (("file", blob[:50000], 49999), errno.EIO),
+                        (("file", blob[:300000], 300128), errno.EIO), (("missing", b"", 10), errno.ENOENT)):
+        specs = base[:3] + [wrong] + base[3:]
+        for lanes in (1, 8):
+            rc, bad, _ = run(specs, lanes)
+            assert rc == code and bad == 3, (wrong[2], lanes, rc, bad)

@@ -414,7 +414,9 @@ typedef struct snaphash_plan_model {
     double host_seconds;     /* modelled makespan of the host part */
     uint64_t host_streams, host_bytes;
     uint32_t host_threads_used;
-    uint32_t reserved;
+    uint32_t host_lane_gain_pct; /* IN (was reserved, 0): what a host thread gains from running its streams eight at a time, a
+                                    stream per AVX-512 lane, in percent of its one-stream rate; 0 or 100 = none.  A ctx plans with
+                                    200 for files and 300 for memory where the CPU has AVX-512F/BW. */
 } snaphash_plan_model;
 int snaphash_plan_streams(const uint64_t *lens, size_t n, snaphash_plan_model *model /* in/out */, uint8_t *on_host /* n, may be NULL */);
 /* CPUs this process may keep busy: affinity mask capped by the cgroup CPU quota (what host_threads = 0 plans with). */

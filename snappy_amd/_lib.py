@@ -64,7 +64,7 @@ class PlanModel(ctypes.Structure):
                 ("host_rate", ctypes.c_double), ("gpu_stream_rate", ctypes.c_double), ("gpu_link", ctypes.c_double),
                 ("gpu_latency", ctypes.c_double),
                 ("gpu_seconds", ctypes.c_double), ("host_seconds", ctypes.c_double), ("host_streams", ctypes.c_uint64),
-                ("host_bytes", ctypes.c_uint64), ("host_threads_used", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("host_bytes", ctypes.c_uint64), ("host_threads_used", ctypes.c_uint32), ("host_lane_gain_pct", ctypes.c_uint32)]
 
 
 class Stats(ctypes.Structure):

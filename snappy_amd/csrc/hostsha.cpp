@@ -5,7 +5,8 @@
 // (the literal one-file helpers.Sha512sum call).  The data.tar.gz producer uses it for the archive digest, the one
 // stream of that pass that cannot be parallel.  Same compression function as the kernels (sha512_core.h,
 // FIPS 180-4), continuing from any chaining value.  This is not a fallback: without a gfx950 device snaphash_init
-// still fails; only SNAPHASH_FLAG_GPU_ONLY keeps this file idle.
+// still fails; only SNAPHASH_FLAG_GPU_ONLY keeps this file idle.  (A pool thread with several streams to hash runs them
+// eight at a time: hostsha_x8.cpp; this file is the one-stream code and the pieces both share.)
 //
 // What it computes is helpers.Sha512sum (reference helpers/helpers.go:187-201):
 // io.Copy in chunks into crypto/sha512, i.e. streaming SHA-512 to EOF.

@@ -13,6 +13,7 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -33,6 +34,7 @@ bool host_sha512_x8_available()
 {
     static const bool ok = [] {
         __builtin_cpu_init();
+        if (getenv("SNAPHASH_NO_X8")) return false; // (A/B runs)
         return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw");
     }();
     return ok;

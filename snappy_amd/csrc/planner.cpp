@@ -80,13 +80,18 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
         const double hs = h_stream(h);
         MinHeap pool;
         for (unsigned t = 0; t < h; ++t) pool.push(0.0);
-        double host_makespan = 0, host_work = 0;
+        double host_makespan = 0, host_work = 0, host_bytes = 0;
+        const double lane_gain = std::max(1.0, m.host_lane_gain);
         for (size_t k = 0; k < n; ++k) {
             // A small file costs its open + close more than its bytes, and that cost is the same lock whoever pays it (the
             // process has one descriptor table): beside a GPU part it stays with the fill threads -- 100 000 x 8 KiB took
             // 148 ms with a quarter of them on host threads against 115 ms whole (profiles/r04_small_files_tree.txt).
             if (m.from_files && lens[order[k]] < kMinHostFile) break;
-            const double c = (double)lens[order[k]] / h_rate + hs;
+            // a stream long against its thread's share keeps the core to itself, the others run eight at a time
+            // (snaphash_api.cpp run_host; the share here is what has moved so far: the long ones move first)
+            host_bytes += (double)lens[order[k]];
+            const bool lanes = lane_gain > 1.0 && k + 1 >= 3u * h && (double)lens[order[k]] < host_bytes / h / 4.0;
+            const double c = (double)lens[order[k]] / (lanes ? h_rate * lane_gain : h_rate) + hs;
             const double t = pool.top() + c;
             pool.pop();
             pool.push(t);
@@ -111,14 +116,18 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
     // no GPU part at all: the fill threads' cores hash too
     if (best_k < n || h_alone > threads) {
         const double hs = h_stream(h_alone);
+        // (every stream's share is known here: who runs eight at a time is the run-time rule itself)
+        const double lane_gain = n >= 3u * h_alone ? std::max(1.0, m.host_lane_gain) : 1.0;
+        const double alone_from = suffix[0] / h_alone / 4.0;
+        auto cost = [&](size_t k) { return (double)lens[order[k]] / ((double)lens[order[k]] < alone_from ? h_rate * lane_gain : h_rate) + hs; };
         double work = 0;
-        for (size_t k = 0; k < n; ++k) work += (double)lens[order[k]] / h_rate + hs;
-        if (std::max(work / h_alone, (double)lens[order[0]] / h_rate + hs) < best * 0.98) { // the lower bound first: the LPT pass is O(n log threads)
+        for (size_t k = 0; k < n; ++k) work += cost(k);
+        if (std::max(work / h_alone, cost(0)) < best * 0.98) { // the lower bound first: the LPT pass is O(n log threads)
             MinHeap pool;
             for (unsigned t = 0; t < h_alone; ++t) pool.push(0.0);
             double mk = 0;
             for (size_t k = 0; k < n && mk < best; ++k) {
-                const double t = pool.top() + (double)lens[order[k]] / h_rate + hs;
+                const double t = pool.top() + cost(k);
                 pool.pop();
                 pool.push(t);
                 mk = std::max(mk, t);

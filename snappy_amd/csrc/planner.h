@@ -29,6 +29,8 @@ struct PlanModel {
     double gpu_per_stream = 0;    // s per stream of batch planning on the engine's thread; 0 = 0.15 us
     double fill_rate = 0;         // B/s ONE fill thread moves into the staging buffers; 0 = 9e9 memory, 6.5e9 files (pread)
     double fill_per_stream = 0;   // s per stream on a fill thread (files: open + close beside eleven others); 0 = 0.3 us memory, 10 us files
+    double host_lane_gain = 1.0;  // what a host thread gains from running its streams eight at a time (hostsha_x8.cpp): x the one-stream rate, for
+                                  // streams short enough to share a core (under a quarter of a thread's share of the host part)
 };
 
 struct PlanResult {

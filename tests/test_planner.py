@@ -140,6 +140,22 @@ def test_small_files_stay_with_the_gpu_part(built_lib):
     assert sum(on_host) == 24 and r["gpu_seconds"] == 0
 
 
+def test_the_plan_counts_what_eight_lanes_add(built_lib):
+    """hostsha_x8.cpp: a host thread with enough streams runs them eight at a time (a ctx plans with 200 % for files, 300 %
+    for memory where the CPU has AVX-512; the exported call takes it as host_lane_gain_pct): a link-bound tree gives more
+    of itself to the host, config 3 is modelled at what 16 threads then do, and a stream that dominates its thread's share
+    still counts at one stream's rate."""
+    lens = [MiB] * 10001
+    _, r1 = _plan(lens, from_files=1)
+    _, r2 = _plan(lens, from_files=1, host_lane_gain_pct=200)
+    assert r2["host_bytes"] > 1.3 * r1["host_bytes"] and max(r2["gpu_seconds"], r2["host_seconds"]) < 0.95 * max(r1["gpu_seconds"], r1["host_seconds"])
+    _, c3 = _plan([1 << 30] * 100, host_lane_gain_pct=300)
+    assert c3["host_streams"] == 100 and c3["host_threads"] == 16 and 1.5 < c3["host_seconds"] < 2.2  # 7 streams a thread at 4.2 GB/s
+    # the archive beside its tree: one stream, one core, one stream's rate -- whatever the gain
+    _, pk = _plan([512 * MiB] + [MiB] * 512, from_files=1, host_lane_gain_pct=200)
+    assert pk["host_streams"] == 1 and abs(pk["host_seconds"] - 512 * MiB / 1.4e9) < 0.02
+
+
 def test_plan_is_deterministic_and_covers_every_stream(built_lib):
     import random
     rng = random.Random(5)

@@ -160,3 +160,15 @@ def test_eight_streams_side_by_side_on_one_core(core, tmp_path_factory):
         for lanes in (1, 8):
             rc, bad, _ = run(specs, lanes)
             assert rc == code and bad == 3, (wrong[2], lanes, rc, bad)
+
+
+def test_eight_streams_under_asan_and_ubsan(tmp_path):
+    """tests/asan_hostsha_x8.cpp: the lane scheduler and the AVX-512 block function with every read checked."""
+    exe = str(tmp_path / "asan_x8")
+    src = [os.path.join(ROOT, "snappy_amd", "csrc", f) for f in ("hostsha.cpp", "hostsha_x8.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                           os.path.join(ROOT, "tests", "asan_hostsha_x8.cpp")] + src + ["-pthread"])
+    work = tmp_path / "files"
+    work.mkdir()
+    r = subprocess.run([exe, str(work)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"asan x8 driver ok" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr.decode()[-3000:])

@@ -952,6 +952,11 @@ def main():
             except Exception as e:  # a time-out or a missing RCCL must not cost the headline
                 inlib = {"error": repr(e)[:400]}
             line["in_library_multi_gpu"] = inlib
+        td = line.get("end_to_end", {}).get("tree_default") if isinstance(line.get("end_to_end"), dict) else None
+        if isinstance(td, dict) and "ms" in td:  # beside `value` (every byte through the kernels): what snaphash_init(NULL) does with the same tree
+            line["default_configuration"] = {"ms": td["ms"], "GiBps": td["GiBps"], "host_bytes": td.get("host_bytes"), "gpu_bytes": td.get("gpu_bytes"),
+                                             "what": "end_to_end.tree_default: the same tree -> hashes.yaml as the library plans it by default (a share of the files on host "
+                                                     "threads beside the PCIe link, eight streams a thread in AVX-512 lanes); never `value`"}
         line["bench_seconds"] = round(time.perf_counter() - t_start, 1)
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()

@@ -431,7 +431,8 @@ uint32_t snaphash_cgroup_cpu_quota(const char *cgroup_root, const char *proc_sel
  * snaphash_shard_rows() x 64 bytes (unused rows zero), the caller all-gathers the slabs in rank order (RCCL:
  * torch.distributed.all_gather_into_tensor or ncclAllGather), and any rank turns world x rows x 64 bytes into
  * hashes.yaml with snaphash_shard_emit (malloc'd; snaphash_free).  plan and emit need no device.  The one-process form
- * of the same thing is snaphash_config.devices. */
+ * of the same thing is snaphash_config.devices.  snaphash_shard_hash plans and fills with the rank's SHARE of the cores
+ * this process may use (the allowance over min(world, visible GPUs)): eight ranks on a node do not each claim all of it. */
 typedef struct snaphash_shard snaphash_shard;
 int snaphash_shard_plan(const char *build_dir, const char *data_tar, uint32_t rank, uint32_t world, snaphash_shard **out);
 size_t snaphash_shard_rows(const snaphash_shard *sh);     /* rows of every rank's slab */

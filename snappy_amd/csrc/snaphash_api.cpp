@@ -148,6 +148,7 @@ struct DevCtx {
     int staging_node = -1;     // node the first staging page was found on after allocation (diagnostic)
     int64_t fd_budget = 0;     // file descriptors a hashing call may keep open between batches (FdCache)
     unsigned fill_cap = 12;    // most fill threads this engine uses (the ctx divides the usable CPUs among its engines)
+    unsigned fill_call_cap = 0; // fewer than that for the call in progress (a rank's share of the node's cores; 0 = no)
     FillPool pool;
 
     snaphash_stats stats{};
@@ -179,6 +180,7 @@ struct snaphash_ctx {
     uint32_t host_threads = 0; // host threads the planner may use: 0 = automatic (the cores this process may keep busy)
     bool gpu_only = false;     // SNAPHASH_FLAG_GPU_ONLY: no planner, every byte through the HIP kernels
     unsigned cpus = 1;         // usable_cpus() at init: affinity mask capped by the cgroup's CPU quota
+    unsigned cpus_call = 0;    // the cores THIS call may plan with (0 = cpus): a rank of a one-process-per-GPU job plans with its share
     double host_rate = 1.4e9;  // bytes/s of one host thread's SHA-512 on this box, measured at init
     uint32_t flags = 0;
     Rccl rccl;
@@ -495,7 +497,8 @@ void run_reads(DevCtx* c, const std::vector<Source>& src, const std::vector<Read
         return (v >= 1 && v <= 256) ? v : 0;
     }();
     const bool from_memory = !ops.empty() && src[ops[0].src].mem != nullptr;
-    const unsigned cap = forced ? (unsigned)forced : std::min(c->fill_cap, from_memory ? 6u : 12u);
+    unsigned cap = forced ? (unsigned)forced : std::min(c->fill_cap, from_memory ? 6u : 12u);
+    if (!forced && c->fill_call_cap) cap = std::min(cap, c->fill_call_cap);
     const unsigned T = (unsigned)std::min<size_t>(cap, std::max<size_t>(1, ops.size() / 4));
     c->pool.parallel_for(ops.size(), T, [&](size_t i) {
         if (first_err.load(std::memory_order_relaxed)) return;
@@ -848,8 +851,9 @@ PlanModel plan_model_of(const snaphash_ctx* x, bool from_files)
 {
     PlanModel m;
     m.n_devices = (unsigned)x->dev.size();
-    m.cpus = x->cpus;
+    m.cpus = x->cpus_call ? x->cpus_call : x->cpus;
     m.fill_threads = std::min(x->d0()->fill_cap, from_files ? 12u : 6u); // what run_reads uses per engine
+    if (x->cpus_call) m.fill_threads = std::max(1u, std::min(m.fill_threads, x->cpus_call > 2u ? x->cpus_call - 1u : 1u));
     if (host_sha512_x8_available()) m.host_lane_gain = from_files ? 2.4 : 3.2; // (measured on the box per pool thread: 3.1 GB/s of files, 4.5 GB/s of memory against 1.26 / 1.4 one stream at a time)
     m.host_threads = x->host_threads;
     m.from_files = from_files;
@@ -949,7 +953,7 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     std::atomic<int> herr{0};
     std::atomic<int64_t> herr_src{-1};
     const unsigned nh = hidx.empty() ? 0u : std::max(1u, std::min<unsigned>(plan_threads, (unsigned)hidx.size()));
-    const bool spare_cores = 2u * nh <= x->cpus; // a long file stream may take a reader thread beside its hasher (hostsha.h)
+    const bool spare_cores = 2u * nh <= (x->cpus_call ? x->cpus_call : x->cpus); // a long file stream may take a reader thread beside its hasher (hostsha.h)
     std::vector<double> hbusy(std::max(1u, nh), 0.0);
     std::stable_sort(hidx.begin(), hidx.end(), [&](uint32_t a, uint32_t b) { return src[a].len > src[b].len; });
     // A thread takes streams off the queue (longest first) and runs up to eight of them side by side, a stream per 64-bit
@@ -1699,6 +1703,24 @@ try {
     if (!x || !sh || !slab) return fail(x, SNAPHASH_EINVAL, "bad argument");
     TOP_ENTER(x);
     memset(slab, 0, sh->rows * 64);
+    // The ranks of a node share its cores: this process sees the whole job's allowance (affinity mask, cgroup quota), and
+    // eight ranks that each planned host threads for all of it would be eight times too many.  A rank plans with its
+    // share -- the allowance over the ranks that can be on this node (at most one per visible GPU).
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
+    const unsigned ranks_here = std::max(1u, std::min<unsigned>(sh->world, (unsigned)ndev));
+    struct Share {
+        snaphash_ctx* x;
+        ~Share()
+        {
+            x->cpus_call = 0;
+            for (auto& d : x->dev) d->fill_call_cap = 0;
+        }
+    } share{x};
+    if (ranks_here > 1) {
+        x->cpus_call = std::max(1u, x->cpus / ranks_here);
+        for (auto& d : x->dev) d->fill_call_cap = std::max(2u, x->cpus_call > 1u ? x->cpus_call - 1u : 1u); // (and its fill threads with it)
+    }
     const int rc = hash_paths(x, sh->my_paths.data(), sh->my_paths.size(), sh->my_sizes.data(), slab, nullptr);
     end_top(x, t_top0_);
     return rc;

@@ -597,6 +597,8 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
                 // (That is a concern of jobs bound by their kernel chain: up to ~2 000 streams, whose 44 MB/s each do not
                 // outrun the link.  With more streams the link is the bound and the first copy should start early: the C2
                 // tree's first batch was a whole 256 MiB buffer, 4 ms of fill with the link idle.)
+                // (Finer steps -- x 1.4 a batch from 16 MiB, eight of them -- were tried for that regime and left the link idle
+                // MORE, 4.5 ms against 3.5: every batch costs ~0.4 ms of planning and hand-over whatever its size.)
                 const uint64_t every = active.size() <= 2048 ? std::min<uint64_t>(S_full, (seg_floor + kAlign) * (uint64_t)active.size()) : 0;
                 S = std::max<uint64_t>({(S_full >> (3 - batch)) & ~(uint64_t)(kAlign - 1), every & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20)});
             }

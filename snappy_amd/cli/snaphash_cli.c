@@ -94,6 +94,10 @@ int main(int argc, char **argv)
         pm.n_devices = cfg.n_devices ? cfg.n_devices : 1;
         pm.host_threads = cfg.host_threads;
         pm.from_files = 1;
+#if defined(__x86_64__)
+        __builtin_cpu_init(); /* as a ctx would plan: where a host thread can run eight streams side by side, it counts on it */
+        if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw")) pm.host_lane_gain_pct = 240;
+#endif
         int prc = snaphash_plan_streams(lens, n, &pm, on_host);
         if (prc) { fprintf(stderr, "snaphash: plan: %s\n", snaphash_strerror(prc)); return 1; }
         for (size_t i = 0; i < n; i++) printf("%s  %s\n", on_host[i] ? "host" : "gpu ", argv[2 + i]);

@@ -313,13 +313,19 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     // (The inner decisions are selects, not branches: every `if` of a divergent wave costs scalar instructions for the
     // exec mask -- the kernel issued as many of those as vector instructions -- and only the ones that skip real work
     // (a link not wanted, a candidate that fails its check word, the extension) are worth them.)
+#if defined(SNAPHASH_DF_GUARDED_LINKS)
+#define SNAPHASH_DF_LINK_GUARD if (more && ncand < left)
+#else
+#define SNAPHASH_DF_LINK_GUARD
+#endif
     while (more && left) {
         uint32_t c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0, ncand = 0;
 #define SNAPHASH_DF_LINK(dst)                                                       \
-        if (more && ncand < left) {                                                 \
+        SNAPHASH_DF_LINK_GUARD {                                                    \
+            const bool want_ = more && ncand < left;                                \
             const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
-            const bool ok_ = d_ != 0u && p - (cur - d_) <= kDfMaxDist;              \
-            more = ok_;                                                             \
+            const bool ok_ = want_ && d_ != 0u && p - (cur - d_) <= kDfMaxDist;     \
+            more = want_ ? ok_ : more;                                              \
             cur = ok_ ? cur - d_ : cur;                                             \
             dst = ok_ ? cur : 0u;                                                   \
             ncand += ok_ ? 1u : 0u;                                                 \

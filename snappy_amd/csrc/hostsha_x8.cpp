@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <memory>
 #include <vector>
 
 #if defined(__x86_64__)
@@ -149,7 +150,7 @@ struct Lane {
     const uint8_t* p = nullptr; // unread bytes in hand ...
     size_t avail = 0;           // ... and how many
     uint64_t file_off = 0;      // files: next byte to read
-    std::vector<uint8_t> buf;   // files: the chunk in hand
+    std::unique_ptr<uint8_t[]> buf; // files: the chunk in hand (kLaneChunk + 128 bytes, not zeroed: a small call should not pay for that)
 };
 
 constexpr size_t kLaneChunk = 256u << 10;
@@ -158,14 +159,14 @@ constexpr size_t kLaneChunk = 256u << 10;
 // the caller's EIO ("the file shrank"), as in host_sha512_file_from
 int lane_refill(Lane& L)
 {
-    if (L.buf.size() < kLaneChunk + 128) L.buf.resize(kLaneChunk + 128);
-    if (L.avail && L.p != L.buf.data()) memmove(L.buf.data(), L.p, L.avail);
-    L.p = L.buf.data();
+    if (!L.buf) L.buf.reset(new uint8_t[kLaneChunk + 128]);
+    if (L.avail && L.p != L.buf.get()) memmove(L.buf.get(), L.p, L.avail);
+    L.p = L.buf.get();
     const uint64_t left = L.src.len - L.file_off;
     size_t want = (size_t)std::min<uint64_t>(left, kLaneChunk);
     while (want) {
         ssize_t r;
-        do r = pread(L.fd, L.buf.data() + L.avail, want, (off_t)L.file_off); while (r < 0 && errno == EINTR);
+        do r = pread(L.fd, L.buf.get() + L.avail, want, (off_t)L.file_off); while (r < 0 && errno == EINTR);
         if (r < 0) return errno;
         if (r == 0) return EIO; // shorter than its size said
         L.avail += (size_t)r;
@@ -262,7 +263,7 @@ int host_sha512_many(unsigned lanes, const std::function<int64_t()>& next, const
             } else {
                 l.fd = open(l.src.path, O_RDONLY | O_CLOEXEC);
                 if (l.fd < 0) { rc = errno; if (err_id) *err_id = id; close_lane(l); break; }
-                l.p = l.buf.data();
+                l.p = l.buf.get();
             }
         }
         if (rc || active == 0) break;

@@ -2,7 +2,9 @@
 """bench.py -- the hashes.yaml SHA-512 pass on MI355X, BASELINE.json's metric.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    (N > 1: one rank per GPU over RCCL.  Under an outer launcher -- torch.distributed.run sets WORLD_SIZE / RANK /
+     LOCAL_RANK -- this process IS a rank; without one the plain command starts its N ranks itself, as child
+     processes, before anything in the parent has touched a GPU: self_launch)
 
 The metric is "GiB/s hashed (whole node), bit-exact hashes.yaml" on the 10 000 x 1 MiB tree (10 001 streams with its
 1 MiB archive stand-in).  SURVEY sec. 8(d) names two timings and says which one that is:
@@ -17,14 +19,15 @@ The metric is "GiB/s hashed (whole node), bit-exact hashes.yaml" on the 10 000 x
        stream-count-bound and flat in N by construction; it is reported, it is not `value`.
 
 Prints ONE JSON line on rank 0.  Beside the two above:
-  parity        hashes.yaml of the timed path byte-identical to the oracle's (N = 1) / to the single-GPU pass and a
-                hashlib sample (N > 1)
+  parity        hashes.yaml of the timed path byte-identical to the oracle's (every N; at N > 1 also to the single-GPU
+                pass), and a hashlib sample
+  config.ranks  world size, backend, launcher and every rank's GPU by PCI bus id: N distinct GPUs, or the line says so
   end_to_end    buffers_sharded (host buffers -> digests, every N); N = 1 also: tree_default (the library's DEFAULT
                 configuration: the planner may give host cores a share), package, build (rows f2 + f3, with the
                 reference-shaped and the all-cores zlib baselines), breakeven (small calls against the reference's loop)
   configs       BASELINE configs 1, 3 and 5 on this GPU: HBM-resident GPU-only pass (roofline per config), the DEFAULT
                 configuration from host memory, the CPU port beside it, sampled parity vs hashlib
-  cpu_baseline  the oracle (C restatement of the reference's serial loop) over the same on-disk tree on one core
+  cpu_baseline  the oracle (C restatement of the reference's serial loop) over the same on-disk tree on one core (every N)
 """
 import argparse
 import ctypes
@@ -187,9 +190,15 @@ def resident_pass(ctx, data_ptr, offsets, lens, slab_ptr, launches, warmup):
     return float(np.mean(k_ms)), wall, st
 
 
-def roofline_of(kernel_ms, nbytes, st, workload, world, note=None):
+def roofline_of(kernel_ms, nbytes, st, workload, world, note=None, streams=None):
     from snappy_amd import _lib
     achieved = nbytes / (kernel_ms * 1e-3) / 1e9
+    if world > 1:
+        scope = ("PER GPU: rank 0's shard (%s streams, %d bytes) resident in ITS HBM against ONE GPU's 8 TB/s; stream-count-bound -- "
+                 "a shard of 1/%d of the streams advances no faster per stream, so achieved and frac fall as 1/N by construction "
+                 "while the launch takes as long as at N = 1 (DESIGN.md sec. 5)" % (streams if streams is not None else "?", int(nbytes), world))
+    else:
+        scope = "per GPU (= the whole job at N = 1): every stream of the workload resident in this GPU's HBM"
     kname = _lib.KERNEL_NAMES.get(st["kernel_used"], "sha512_wide_kernel")
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % kname.replace("<", "_").replace(">", ""))
@@ -200,11 +209,41 @@ def roofline_of(kernel_ms, nbytes, st, workload, world, note=None):
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": kname, "kernel_ms": round(kernel_ms, 4), "bytes_per_launch": int(nbytes),
+            "scope": scope, "n_gpus": world, "kernel": kname, "kernel_ms": round(kernel_ms, 4), "bytes_per_launch": int(nbytes),
             "launches_per_pass": int(st["launches"]), "sha512_blocks_per_pass": int(st["blocks"]),
             "frac_of_valu_ceiling": round(achieved / VALU_SATURATED_GBPS, 4),
             "note": note or "algorithmic bytes = file bytes hashed by rank 0's launch, inputs resident in HBM; SHA-512 is "
                             "integer-VALU and stream-count bound, not HBM bound (DESIGN.md sec. 4)"}
+
+
+# ------------------------------------------------------------------------------------------
+# the planner's prediction beside what the call took (snaphash_stats_ex, ABI 5)
+# ------------------------------------------------------------------------------------------
+def model_vs_actual(ex, tolerance=0.25):
+    """the plan's modelled makespans next to the measured ones.  `off` names every side whose
+    prediction missed by more than `tolerance` -- on another box (PCIe generation, CPU, quota) that is the sign that the
+    model's constants do not hold there; the calibration (planner.h PlanCalib) then moves them."""
+    rows = {}
+    off = []
+    for side, planned, actual in (("gpu", ex.get("planned_gpu_ms", 0.0), ex.get("gpu_ms", 0.0)),
+                                  ("host", ex.get("planned_host_ms", 0.0), ex.get("host_ms", 0.0))):
+        if planned <= 0 and actual <= 0:
+            continue
+        rows[side] = {"planned_ms": round(planned, 3), "actual_ms": round(actual, 3)}
+        if planned > 0 and actual > 0:
+            rows[side]["actual_over_planned"] = round(actual / planned, 3)
+            # (sub-millisecond parts are start-up noise either way)
+            if max(planned, actual) >= 1.0 and not (1 - tolerance) <= actual / planned <= 1 / (1 - tolerance):
+                off.append(side)
+    whole_p = max(ex.get("planned_gpu_ms", 0.0), ex.get("planned_host_ms", 0.0))
+    rows["call"] = {"planned_ms": round(whole_p, 3), "hash_ms": round(ex.get("hash_ms", 0.0), 3), "plan_ms": round(ex.get("plan_ms", 0.0), 3),
+                    "threads_planned": int(ex.get("planned_threads", 0)), "threads_run": int(ex.get("host_threads_run", 0))}
+    if whole_p > 0 and ex.get("hash_ms", 0.0) > 0:
+        rows["call"]["actual_over_planned"] = round(ex["hash_ms"] / whole_p, 3)
+        if max(whole_p, ex["hash_ms"]) >= 1.0 and not (1 - tolerance) <= ex["hash_ms"] / whole_p <= 1 / (1 - tolerance):
+            off.append("call")
+    rows["off_by_more_than_%d_pct" % int(tolerance * 100)] = off
+    return rows
 
 
 # ------------------------------------------------------------------------------------------
@@ -262,12 +301,14 @@ def e2e_tree_default(build, tar, total, want_yaml, device):
                 best = (dt, c.stats(), c.stats_ex())
         if want_yaml is not None and y != want_yaml:
             raise SystemExit("PARITY FAILURE: default-configuration hashes.yaml differs from the GPU-only pass")
+        plan_model = dict(c.plan_model(True), calibration=c.calib())  # what this ctx plans file sources with, after these passes
     dt, st, ex = best
     return {"what": "the same on-disk tree -> snaphash_tree, DEFAULT configuration (snaphash_init(NULL)): planned, the host "
                     "cores beside the staging fill take a share (the library's own SHA-512, hostsha.cpp)",
             "ms": round(dt * 1e3, 2), "GiBps": round(total / GiB / dt, 2), "gpu_bytes": int(ex["gpu_bytes"]),
             "host_bytes": int(ex["host_bytes"]), "host_streams": int(ex["host_streams"]), "host_ms": round(ex["host_ms"], 1),
             "h2d_ms": round(st["h2d_ms"], 2), "kernel_ms": round(st["kernel_ms"], 2),
+            "model_vs_actual": model_vs_actual(ex), "plan_model": plan_model,
             "parity": "hashes.yaml byte-identical to the GPU-only pass (and so to the oracle's)", "best_of": 5}
 
 
@@ -315,6 +356,7 @@ def e2e_package(total_mib=512):
                 "bytes": total, "ms": round(dt * 1e3, 1), "GiBps": round(total / GiB / dt, 2),
                 "gpu_bytes": int(ex["gpu_bytes"]), "host_bytes": int(ex["host_bytes"]), "host_streams": int(ex["host_streams"]),
                 "host_ms": round(ex["host_ms"], 1), "kernel_ms": round(st["kernel_ms"], 1),
+                "model_vs_actual": model_vs_actual(ex),
                 "cpu_port_serial_ms": round(dt_c * 1e3, 1),
                 "parity": "hashes.yaml byte-identical to the oracle's", "best_of": 3}
     finally:
@@ -365,6 +407,7 @@ def e2e_breakeven():
                              "library_default_ms": round(min(ts) * 1e3, 3), "first_call_ms": round(first * 1e3, 3),
                              "reference_serial_port_ms": round(min(to) * 1e3, 3),
                              "ratio": round(min(to) / min(ts), 2), "gpu_bytes": int(ex["gpu_bytes"]), "host_bytes": int(ex["host_bytes"]),
+                             "model_vs_actual": model_vs_actual(ex),
                              "not_slower": bool(min(ts) <= min(to))})
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
@@ -585,7 +628,8 @@ def config_leg(name, device, kern, cpu_budget_s):
     out["default_config"] = {"what": "host buffers -> snaphash_sha512_buffers, DEFAULT configuration (planned: planner.h)",
                              "ms": round(dt * 1e3, 2), "GiBps": round(total / GiB / dt, 2), "gpu_bytes": int(ex["gpu_bytes"]),
                              "host_bytes": int(ex["host_bytes"]), "host_streams": int(ex["host_streams"]), "host_ms": round(ex["host_ms"], 1),
-                             "kernel_ms": round(st["kernel_ms"], 2), "h2d_ms": round(st["h2d_ms"], 2), "usable_cpus": cpus}
+                             "kernel_ms": round(st["kernel_ms"], 2), "h2d_ms": round(st["h2d_ms"], 2), "usable_cpus": cpus,
+                             "model_vs_actual": model_vs_actual(ex)}
     order = list(np.argsort(-sizes.astype(np.int64))[:1]) + [int(x) for x in rng.permutation(n)[:4000]] if name == "C5" else None
     out["cpu_port"] = cpu_port_sample(host, offsets, sizes, cpu_budget_s, order)
     if name == "C5":
@@ -601,8 +645,72 @@ def config_leg(name, device, kern, cpu_budget_s):
 
 
 # ------------------------------------------------------------------------------------------
+# --gpus N > 1 without an outer launcher: the parent starts the ranks itself
+# ------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python3 bench.py --gpus N` by itself (no torch.distributed.run around it): N rank processes as CHILDREN of this
+    one, the rendezvous variables in their environment, rank 0's stdout (the ONE JSON line) relayed, every other rank's
+    stdout sent to stderr.  Runs before torch, snappy_amd or anything else that could touch a GPU is imported here, and
+    never replaces this process (no exec): the parent only waits.  If a rank fails the others are ended (their exact
+    PIDs) and the parent exits with that rank's code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SNAPHASH_BENCH_SELF_LAUNCHED": "1",
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        for r in sorted(live):
+            procs[r].terminate()
+        deadline = time.time() + 20
+        for r in sorted(live):
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    reader.join(timeout=10)
+    text = (out0[0] if out0 else b"").decode(errors="replace")
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with %d; the other ranks were ended\n" % failed)
+        return failed[1] if 0 < failed[1] < 256 else 1
+    if not any(l.startswith("{") for l in text.splitlines()):
+        sys.stderr.write("bench.py: the ranks ended without a JSON line from rank 0\n")
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # nothing above this line has imported torch or the library
     # stdout carries ONE JSON line and nothing else: whatever the libraries below print there (RCCL's version banner
     # at the first collective, for one) goes to stderr
     sys.stdout.flush()
@@ -618,25 +726,36 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        if world == 1 and args.gpus > 1:  # (only an environment that SETS WORLD_SIZE=1 gets here: unset, the ranks are self-launched)
+            raise SystemExit("--gpus %d under WORLD_SIZE=1: unset WORLD_SIZE (bench.py then starts its own ranks) or launch %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback exists)"
     # SNAPHASH_BENCH_SAME_GPU=1: every rank on GPU 0, control plane and digest gather over gloo (RCCL refuses two ranks on
     # one device): how a 1-GPU box rehearses the N > 1 path.  SNAPHASH_BENCH_FORCE_DIST=1: the RCCL path with one rank.
     same_gpu = os.environ.get("SNAPHASH_BENCH_SAME_GPU") == "1"
     # LOCAL_RANK names the rank's GPU; a launcher that hands every rank ONE visible device (ordinal 0) is accommodated
-    device = 0 if same_gpu else local_rank % max(1, torch.cuda.device_count())
+    visible = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if not same_gpu and world > 1 and visible < local_world and visible != 1:
+        # (visible == 1: a launcher that hands every rank ONE device of its own; anything else would put two ranks on one
+        # GPU, which RCCL refuses later and less legibly)
+        raise SystemExit("%d ranks on this node but %d GPUs visible: one rank per GPU is the contract (SNAPHASH_BENCH_SAME_GPU=1 "
+                         "rehearses N ranks on one GPU over gloo)" % (local_world, visible))
+    device = 0 if same_gpu else local_rank % max(1, visible)
     torch.cuda.set_device(device)
     force_dist = os.environ.get("SNAPHASH_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
     use_dist = world > 1 or force_dist
     coll_device = None if same_gpu else "cuda"
+    backend = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if same_gpu else "nccl"
         if same_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    # what moves the digest slabs, under its own name: backend "nccl" IS RCCL on ROCm; the one-GPU rehearsal runs over gloo
+    coll_name = {"nccl": "RCCL", "gloo": "gloo (CPU tensors: the same-GPU rehearsal)", None: "none"}[backend]
 
     def fence():
         if use_dist:
@@ -765,6 +884,10 @@ def main():
                                     "kernel_ms": round(e_st["kernel_ms"], 2), "launches": int(e_st["launches"])})
         ms_step = elapsed / args.steps * 1e3
         value = total_bytes / GiB / (elapsed / args.steps)
+        # who took part: every rank's GPU by its PCI bus id (snaphash_get_engine_info), N distinct ones or the line says so
+        e_info = ectx.engine_info(0)
+        rank_ids = gather_obj({"rank": rank, "local_rank": local_rank, "device": device, "pci_bus_id": e_info["pci_bus_id"],
+                               "numa_node": e_info["numa_node"], "pid": os.getpid(), "host": os.uname().nodename})
 
         # ---- parity of the timed path, outside the timed region ----------------------------------------------------
         parity, cpu, oracle_yaml = None, None, None
@@ -781,23 +904,27 @@ def main():
                 y1 = ectx.tree(build, tar)
                 if y1 != y:
                     raise SystemExit("PARITY FAILURE: the sharded pass's hashes.yaml differs from the single-GPU snaphash_tree's")
-                parity["result"] = "hashes.yaml of the %d-rank pass byte-identical to the single-GPU snaphash_tree's" % world
-            if args.cpu_seconds > 0 and (world == 1 and not force_dist):
+                parity["single_gpu"] = "hashes.yaml of the %d-rank pass byte-identical to the single-GPU snaphash_tree's" % world
+            if args.cpu_seconds > 0:
+                # at every N: the oracle's own serial pass over the same on-disk tree is both the checker of the timed path's
+                # hashes.yaml and the cpu_baseline (rank 0, outside the timed region; the other ranks wait at the next fence)
                 from oracle import oracle
                 t0 = time.perf_counter()
                 oracle_yaml = oracle.hashes_yaml(build, tar)
                 dt_c = time.perf_counter() - t0
                 if oracle_yaml != y:
                     raise SystemExit("PARITY FAILURE: hashes.yaml differs from the oracle's")
-                parity["result"] = "hashes.yaml byte-identical to the oracle's (%d records)" % y.count(b"- name: ")
+                parity["result"] = "hashes.yaml%s byte-identical to the oracle's (%d records)" % (
+                    " of the %d-rank pass" % world if world > 1 else "", y.count(b"- name: "))
                 cpu = {"value": round(total_bytes / GiB / dt_c, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
                        "sample": "the oracle's whole writeHashes pass (walk, 32 KiB reads, SHA-512, YAML) over the same on-disk "
                                  "tree of %d files / %.0f MiB: %.1f s on one core, as the reference's single goroutine would run it" %
                                  (n_files + 1, total_bytes / 2**20, dt_c),
                        "host_cores_visible": os.cpu_count(), "usable_cpus": int(_lib.lib().snaphash_usable_cpus())}
-                cpu["all_cores"] = cpu_pool_leg(sizes, 3.0)
+                if world == 1:
+                    cpu["all_cores"] = cpu_pool_leg(sizes, 3.0)
             elif "result" not in parity:
-                parity["result"] = "hashlib sample only (--cpu-seconds 0)"
+                parity["result"] = parity.get("single_gpu", "hashlib sample only") + " (--cpu-seconds 0: no oracle pass)"
 
         # ---- end_to_end legs ------------------------------------------------------------------------------------------
         end_to_end, configs = {}, None
@@ -888,9 +1015,18 @@ def main():
                 leg(configs, name, lambda nm=name: config_leg(nm, device, kern, 3.0 if args.cpu_seconds > 0 else 0.0))
 
         if rank == 0:
-            wl = "%s: ONE on-disk tree (tmpfs) of %d files%s -> hashes.yaml, sharded over %d GPU(s)%s" % (
+            distinct = len(set((r["host"], r["pci_bus_id"]) for r in rank_ids))
+            wl = "%s: ONE on-disk tree (tmpfs) of %d files%s -> hashes.yaml, sharded over %d rank(s) on %d distinct GPU(s)%s" % (
                 args.workload, n_files + 1, " (10 000 x 1 MiB + the 1 MiB archive stand-in)" if args.workload == "C2" else "",
-                world, ", RCCL all-gather of the digest slabs" if world > 1 else "")
+                world, distinct, ", %s all-gather of the digest slabs" % coll_name if use_dist else "")
+            ranks = {"world_size": dist.get_world_size() if use_dist else 1, "backend": backend, "collective": coll_name,
+                     "launcher": "bench.py's own child processes" if os.environ.get("SNAPHASH_BENCH_SELF_LAUNCHED") == "1"
+                                 else ("outer launcher (torch.distributed.run or alike)" if "RANK" in os.environ else "single process"),
+                     "gpus": rank_ids, "distinct_gpus": distinct,
+                     "one_gpu_per_rank": bool(distinct == world)}
+            if distinct != world:
+                ranks["note"] = ("%d ranks SHARE %d GPU(s): a rehearsal of the N > 1 path (SNAPHASH_BENCH_SAME_GPU), not a "
+                                 "multi-GPU measurement -- `value` here says nothing about scaling" % (world, distinct))
             line = {
                 "metric": "GiB/s hashed (whole node), bit-exact hashes.yaml, 10k x 1 MiB tree" if args.workload == "C2"
                           else "GiB/s hashed (whole node), bit-exact hashes.yaml, workload %s" % args.workload,
@@ -898,15 +1034,15 @@ def main():
                 "value_kind": "end_to_end (SURVEY sec. 8d-ii): walk + pread + pinned staging + H2D over PCIe + HIP kernels + "
                               "hashes.yaml, every byte hashed by the kernels; " +
                               ("snaphash_tree on one GPU" if world == 1 and not force_dist else
-                               "every rank its LPT share of the ONE tree (snaphash_shard_*), one RCCL all-gather, rank 0 writes the YAML") +
+                               "every rank its LPT share of the ONE tree (snaphash_shard_*), one all-gather of the slabs over %s, rank 0 writes the YAML" % coll_name) +
                               ".  The HBM-resident rate is `hbm_resident` / `roofline`, never `value`",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": wl, "files": n_files + 1, "bytes": total_bytes, "kernel": _lib.KERNEL_NAMES.get(r_st["kernel_used"], "?"),
-                           "per_rank": per_rank_step, "tree_placement": numa_note, "tree_home": tree_home,
+                           "ranks": ranks, "per_rank": per_rank_step, "tree_placement": numa_note, "tree_home": tree_home,
                            "step_ms_rank0": {"min": round(min(step_ms), 2), "median": round(sorted(step_ms)[len(step_ms) // 2], 2), "max": round(max(step_ms), 2)}},
-                "roofline": roofline_of(k_ms, int(my_lens.sum()), r_st, args.workload, world),
+                "roofline": roofline_of(k_ms, int(my_lens.sum()), r_st, args.workload, world, streams=len(my_paths)),
                 "hbm_resident": {"what": "the same streams already in HBM (snaphash_sha512_device), every rank its share; wall per pass, MAX over ranks",
                                  "ms_per_pass": round(r_wall * 1e3, 4), "GiBps": round(total_bytes / GiB / r_wall, 3),
                                  "launches_timed": args.resident_steps,
@@ -957,6 +1093,26 @@ def main():
             line["default_configuration"] = {"ms": td["ms"], "GiBps": td["GiBps"], "host_bytes": td.get("host_bytes"), "gpu_bytes": td.get("gpu_bytes"),
                                              "what": "end_to_end.tree_default: the same tree -> hashes.yaml as the library plans it by default (a share of the files on host "
                                                      "threads beside the PCIe link, eight streams a thread in AVX-512 lanes); never `value`"}
+        # the planner's conscience in one place: every planned leg's prediction against what it took, and which missed by > 25 %
+        def mva_rows(node, path, out):
+            if isinstance(node, dict):
+                if "model_vs_actual" in node and isinstance(node["model_vs_actual"], dict):
+                    m = node["model_vs_actual"]
+                    out[path or "."] = {"call": m.get("call"), "off": m.get("off_by_more_than_25_pct", [])}
+                for k, v in node.items():
+                    if k != "model_vs_actual":
+                        mva_rows(v, (path + "." if path else "") + str(k), out)
+            elif isinstance(node, list):
+                for i, v in enumerate(node):
+                    mva_rows(v, "%s[%s]" % (path, v.get("tree", i) if isinstance(v, dict) else i), out)
+        rows = {}
+        mva_rows(line.get("end_to_end"), "end_to_end", rows)
+        mva_rows(line.get("configs"), "configs", rows)
+        if rows:
+            line["planner"] = {"what": "snaphash_stats_ex (ABI 5): the plan's modelled makespan beside the measured one for every leg that "
+                                       "ran in the default (planned) configuration; the model's link and fill rates are calibrated on "
+                                       "this box (snaphash_get_calib), see end_to_end.tree_default.plan_model",
+                               "rows": rows, "rows_off_by_more_than_25_pct": sorted(k for k, v in rows.items() if v["off"])}
         line["bench_seconds"] = round(time.perf_counter() - t_start, 1)
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()

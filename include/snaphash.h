@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SNAPHASH_ABI_VERSION 4
+#define SNAPHASH_ABI_VERSION 5
 
 enum {
     SNAPHASH_OK = 0,
@@ -154,6 +154,18 @@ typedef struct snaphash_stats_ex { /* of the most recent hashing call on the ctx
     uint64_t reserved3;    /* (ABI 2 declared a mid-stream hand-over counter here that was never implemented: whole
                               streams move or none) */
     double host_ms;        /* busiest host thread, host clock */
+    /* ---- ABI 5 (filled when struct_size covers them; an ABI 4 caller's shorter struct is still accepted): what the
+     * planner PREDICTED for the call set beside what the call then took.  A prediction off by more than a quarter says
+     * that the model's constants do not describe this box (another PCIe generation, CPU or quota): snaphash_get_plan_model
+     * shows them, and they are corrected from what the calls measure (planner.h PlanCalib). ---- */
+    double planned_gpu_ms;  /* modelled makespan of the GPU part (0 = no plan: SNAPHASH_FLAG_GPU_ONLY, or no GPU part) */
+    double planned_host_ms; /* modelled makespan of the host part (0 = none) */
+    uint32_t planned_threads; /* host threads the plan asked for */
+    uint32_t host_threads_run; /* host threads that ran (fewer when descriptors are short: snaphash.h, RLIMIT_NOFILE) */
+    double gpu_ms;          /* actual: the GPU part from its first fill to its last digest, slowest engine, host clock */
+    double hash_ms;         /* actual: planning + both parts + gather (the whole hashing step of the call; wall_ms of
+                               snaphash_stats also holds the walk and the YAML of a tree call) */
+    double plan_ms;         /* of that, the planner itself */
 } snaphash_stats_ex;
 
 /* ---- lifetime -------------------------------------------------------------- */
@@ -416,9 +428,30 @@ typedef struct snaphash_plan_model {
     uint32_t host_threads_used;
     uint32_t host_lane_gain_pct; /* IN (was reserved, 0): what a host thread gains from running its streams eight at a time, a
                                     stream per AVX-512 lane, in percent of its one-stream rate; 0 or 100 = none.  A ctx plans with
-                                    200 for files and 300 for memory where the CPU has AVX-512F/BW. */
+                                    240 for files and 320 for memory where the CPU has AVX-512F/BW (snaphash_get_plan_model
+                                    returns what it uses). */
+    /* ---- ABI 5 (read when struct_size covers it) ---- */
+    double fill_rate;        /* IN: B/s ONE staging-fill thread moves (0 = 9e9 from memory, 6.5e9 pread of files) */
 } snaphash_plan_model;
 int snaphash_plan_streams(const uint64_t *lens, size_t n, snaphash_plan_model *model /* in/out */, uint8_t *on_host /* n, may be NULL */);
+/* ABI 5: the model `ctx` plans a call with right now -- cores, threads, the host rate measured at init, and the link and
+ * fill rates as calibrated on this box so far (at init, then by every staged call) -- so that snaphash_plan_streams
+ * reproduces the ctx's own plan.  model->struct_size in; the out fields are zeroed. */
+int snaphash_get_plan_model(const snaphash_ctx *ctx, int from_files, snaphash_plan_model *model);
+/* ABI 5, host-only: the calibration's update rule by itself (what a ctx applies after each staged call): an observation
+ * of `bytes` moved in `seconds` -- what = 0: an engine's H2D copies (HIP event time), 1: one fill thread from memory,
+ * 2: one fill thread preading files (wall x threads).  Returns 1 when the observation was taken, 0 when it was too
+ * small or implausible to mean anything, negative on bad arguments.  snaphash_calib_apply writes the calibrated
+ * gpu_link / fill_rate into a model that has not set them (from_files decides which). */
+typedef struct snaphash_plan_calib {
+    uint32_t struct_size; /* in: sizeof(snaphash_plan_calib) */
+    uint32_t n_dma, n_fill_mem, n_fill_files; /* observations taken */
+    double dma;           /* B/s, 0 = not measured */
+    double fill_mem, fill_files;
+} snaphash_plan_calib;
+int snaphash_calib_observe(snaphash_plan_calib *calib, int what, double bytes, double seconds);
+int snaphash_calib_apply(const snaphash_plan_calib *calib, snaphash_plan_model *model);
+int snaphash_get_calib(const snaphash_ctx *ctx, snaphash_plan_calib *out); /* what ctx has measured so far */
 /* CPUs this process may keep busy: affinity mask capped by the cgroup CPU quota (what host_threads = 0 plans with). */
 uint32_t snaphash_usable_cpus(void);
 /* the quota part alone, on any cgroup tree (tests): whole CPUs, 0 = none found */
@@ -432,7 +465,13 @@ uint32_t snaphash_cgroup_cpu_quota(const char *cgroup_root, const char *proc_sel
  * torch.distributed.all_gather_into_tensor or ncclAllGather), and any rank turns world x rows x 64 bytes into
  * hashes.yaml with snaphash_shard_emit (malloc'd; snaphash_free).  plan and emit need no device.  The one-process form
  * of the same thing is snaphash_config.devices.  snaphash_shard_hash plans and fills with the rank's SHARE of the cores
- * this process may use (the allowance over min(world, visible GPUs)): eight ranks on a node do not each claim all of it. */
+ * this process may use, the allowance over the ranks on THIS node: eight ranks on a node do not each claim all of it.
+ * How many ranks share the node comes from the caller -- snaphash_shard_set_local_ranks (ABI 5), else the launcher's
+ * LOCAL_WORLD_SIZE (torch.distributed.run, mpirun's OMPI_COMM_WORLD_LOCAL_SIZE) -- and only without either from
+ * min(world, visible GPUs), which is wrong under a launcher that shows every rank ONE device.
+ * Every rank must have walked the SAME tree: snaphash_shard_fingerprint (ABI 5) is a 64-bit hash of the plan (names,
+ * sizes, modes, who hashes what) for the caller to compare across ranks BEFORE the all-gather -- a tree that changed
+ * between two ranks' walks otherwise ends in mismatched slabs or a hung collective (snappy_amd/sharded.py does it). */
 typedef struct snaphash_shard snaphash_shard;
 int snaphash_shard_plan(const char *build_dir, const char *data_tar, uint32_t rank, uint32_t world, snaphash_shard **out);
 size_t snaphash_shard_rows(const snaphash_shard *sh);     /* rows of every rank's slab */
@@ -444,6 +483,8 @@ int snaphash_shard_hash(snaphash_ctx *ctx, snaphash_shard *sh, uint8_t *slab /* 
 int snaphash_shard_emit(const snaphash_shard *sh, const uint8_t *slabs /* world * rows * 64, rank-major */,
                         char **yaml_out, size_t *yaml_len);
 void snaphash_shard_free(snaphash_shard *sh);
+int snaphash_shard_set_local_ranks(snaphash_shard *sh, uint32_t ranks_on_this_node /* 0 = as found (see above) */);
+uint64_t snaphash_shard_fingerprint(const snaphash_shard *sh);
 
 /* Host-only: the topology probe the engines use, on any sysfs tree (the tests hand in a fake one).  *node = NUMA node
  * of the PCI function (-1 unknown); cpus (may be NULL) receives up to cap CPU numbers of that node, *n_cpus how many

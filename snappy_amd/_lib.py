@@ -33,6 +33,9 @@ EXPORTS = [
     "snaphash_get_engine_cpus", "snaphash_numa_slice", "snaphash_plan_streams", "snaphash_usable_cpus", "snaphash_cgroup_cpu_quota",
     "snaphash_shard_plan", "snaphash_shard_rows", "snaphash_shard_count", "snaphash_shard_streams", "snaphash_shard_bytes",
     "snaphash_shard_path", "snaphash_shard_hash", "snaphash_shard_emit", "snaphash_shard_free",
+    # ABI 5
+    "snaphash_shard_set_local_ranks", "snaphash_shard_fingerprint", "snaphash_get_plan_model",
+    "snaphash_calib_observe", "snaphash_calib_apply", "snaphash_get_calib",
 ]
 FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER, FLAG_GPU_ONLY, FLAG_NO_NUMA, FLAG_KEEP_RLIMIT = 1, 2, 4, 8, 16, 32
 
@@ -49,7 +52,11 @@ class StatsEx(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("n_devices", ctypes.c_uint32), ("gather_kind", ctypes.c_uint32),
                 ("gather_checked", ctypes.c_uint32), ("gather_ms", ctypes.c_double), ("gpu_bytes", ctypes.c_uint64),
                 ("host_bytes", ctypes.c_uint64), ("host_streams", ctypes.c_uint64), ("reserved3", ctypes.c_uint64),
-                ("host_ms", ctypes.c_double)]
+                ("host_ms", ctypes.c_double),
+                # ABI 5: the plan's prediction beside what the call took
+                ("planned_gpu_ms", ctypes.c_double), ("planned_host_ms", ctypes.c_double), ("planned_threads", ctypes.c_uint32),
+                ("host_threads_run", ctypes.c_uint32), ("gpu_ms", ctypes.c_double), ("hash_ms", ctypes.c_double),
+                ("plan_ms", ctypes.c_double)]
 
 
 class EngineInfo(ctypes.Structure):
@@ -64,7 +71,14 @@ class PlanModel(ctypes.Structure):
                 ("host_rate", ctypes.c_double), ("gpu_stream_rate", ctypes.c_double), ("gpu_link", ctypes.c_double),
                 ("gpu_latency", ctypes.c_double),
                 ("gpu_seconds", ctypes.c_double), ("host_seconds", ctypes.c_double), ("host_streams", ctypes.c_uint64),
-                ("host_bytes", ctypes.c_uint64), ("host_threads_used", ctypes.c_uint32), ("host_lane_gain_pct", ctypes.c_uint32)]
+                ("host_bytes", ctypes.c_uint64), ("host_threads_used", ctypes.c_uint32), ("host_lane_gain_pct", ctypes.c_uint32),
+                ("fill_rate", ctypes.c_double)]  # ABI 5
+
+
+class PlanCalib(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("n_dma", ctypes.c_uint32), ("n_fill_mem", ctypes.c_uint32),
+                ("n_fill_files", ctypes.c_uint32), ("dma", ctypes.c_double), ("fill_mem", ctypes.c_double),
+                ("fill_files", ctypes.c_double)]
 
 
 class Stats(ctypes.Structure):
@@ -183,6 +197,13 @@ def lib():
     L.snaphash_numa_slice.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32, vp, sz, ctypes.POINTER(sz)]
     L.snaphash_get_engine_cpus.argtypes = [vp, ctypes.c_uint32, vp, sz, ctypes.POINTER(sz)]
     L.snaphash_plan_streams.argtypes = [u64p, sz, ctypes.POINTER(PlanModel), vp]
+    L.snaphash_shard_set_local_ranks.argtypes = [vp, ctypes.c_uint32]
+    L.snaphash_shard_fingerprint.argtypes = [vp]
+    L.snaphash_shard_fingerprint.restype = ctypes.c_uint64
+    L.snaphash_get_plan_model.argtypes = [vp, ctypes.c_int, ctypes.POINTER(PlanModel)]
+    L.snaphash_calib_observe.argtypes = [ctypes.POINTER(PlanCalib), ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    L.snaphash_calib_apply.argtypes = [ctypes.POINTER(PlanCalib), ctypes.POINTER(PlanModel)]
+    L.snaphash_get_calib.argtypes = [vp, ctypes.POINTER(PlanCalib)]
     L.snaphash_usable_cpus.argtypes = []
     L.snaphash_usable_cpus.restype = ctypes.c_uint32
     L.snaphash_cgroup_cpu_quota.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
@@ -419,6 +440,19 @@ class Context:
         s = StatsEx(ctypes.sizeof(StatsEx))
         self._check(lib().snaphash_get_stats_ex(self._h, ctypes.byref(s)))
         return {f[0]: getattr(s, f[0]) for f in StatsEx._fields_}
+
+    def plan_model(self, from_files):
+        """snaphash_get_plan_model: what this ctx plans a call with right now (calibrated link and fill rates included);
+        its fields are keyword arguments of plan_streams()."""
+        pm = PlanModel(ctypes.sizeof(PlanModel))
+        self._check(lib().snaphash_get_plan_model(self._h, 1 if from_files else 0, ctypes.byref(pm)))
+        return {k: getattr(pm, k) for k in ("n_devices", "cpus", "fill_threads", "host_threads", "from_files", "host_rate",
+                                            "gpu_stream_rate", "gpu_link", "gpu_latency", "host_lane_gain_pct", "fill_rate")}
+
+    def calib(self):
+        c = PlanCalib(ctypes.sizeof(PlanCalib))
+        self._check(lib().snaphash_get_calib(self._h, ctypes.byref(c)))
+        return {f[0]: getattr(c, f[0]) for f in PlanCalib._fields_ if f[0] != "struct_size"}
 
     def engine_info(self, i):
         e = EngineInfo(ctypes.sizeof(EngineInfo))

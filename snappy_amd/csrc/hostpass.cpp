@@ -462,6 +462,7 @@ int parse_yaml(const char* text, size_t len, ParsedHashes& out)
                 };
                 for (unsigned t = 1; t < T; ++t) th.spawn(work, t);
                 work(0);
+                th.join_all(); // raises what a worker threw (an allocation that failed): a lost worker must not read as a clean, short file list
             }
             bool clean = true;
             for (unsigned t = 0; t < T; ++t) clean = clean && prc[t] == SNAPHASH_OK && !top[t];

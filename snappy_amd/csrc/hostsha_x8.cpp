@@ -192,7 +192,16 @@ int host_sha512_many(unsigned lanes, const std::function<int64_t()>& next, const
             host_sha512_final(hs, s.digest);
             return 0;
         }
-        const int err = host_sha512_file_from(hs, s.path, 0, s.len, s.digest, s.read_ahead);
+        // The process is out of descriptors (EMFILE) or the system is (ENFILE): the reference's loop, one file open at a time
+        // (helpers.go:189-194), would have gone through -- other threads' lanes and the staging fill's kept descriptors
+        // (FdCache) are what holds them, and they let go as their streams end.  Wait for that, a bounded while.
+        int err = 0;
+        for (unsigned tries = 0;; ++tries) {
+            host_sha512_init(hs);
+            err = host_sha512_file_from(hs, s.path, 0, s.len, s.digest, s.read_ahead);
+            if ((err != EMFILE && err != ENFILE) || tries >= 4000) break;
+            usleep(tries < 100 ? 200 : 2000);
+        }
         if (err && err_id) *err_id = id;
         return err;
     };
@@ -203,6 +212,7 @@ int host_sha512_many(unsigned lanes, const std::function<int64_t()>& next, const
         }
         return 0;
     }
+    std::vector<int64_t> deferred; // streams whose open met EMFILE / ENFILE while lanes were busy: one at a time, when the lanes have drained
 
     alignas(64) uint64_t S[64];
     static const std::vector<uint8_t> zeros(kLaneChunk, 0);
@@ -262,7 +272,14 @@ int host_sha512_many(unsigned lanes, const std::function<int64_t()>& next, const
                 l.avail = (size_t)l.src.len;
             } else {
                 l.fd = open(l.src.path, O_RDONLY | O_CLOEXEC);
-                if (l.fd < 0) { rc = errno; if (err_id) *err_id = id; close_lane(l); break; }
+                if (l.fd < 0) {
+                    const int e = errno;
+                    close_lane(l);
+                    if (e == EMFILE || e == ENFILE) { deferred.push_back(id); --k; continue; } // (the lane stays free; the stream waits)
+                    rc = e;
+                    if (err_id) *err_id = id;
+                    break;
+                }
                 l.p = l.buf.get();
             }
         }
@@ -297,7 +314,16 @@ int host_sha512_many(unsigned lanes, const std::function<int64_t()>& next, const
                 host_sha512_resume(hs, H, l.done);
                 host_sha512_update(hs, l.p, l.avail);
                 if (l.fd >= 0) {
-                    rc = host_sha512_file_from(hs, l.src.path, l.file_off, l.src.len, l.src.digest, false);
+                    // (the file is opened again by its path: the lane's own descriptor goes first, so that a thread never
+                    // needs two for one stream; HostSha is a plain value -- a try that found no descriptor starts from a copy)
+                    close(l.fd);
+                    l.fd = -1;
+                    for (unsigned tries = 0;; ++tries) {
+                        HostSha h2 = hs;
+                        rc = host_sha512_file_from(h2, l.src.path, l.file_off, l.src.len, l.src.digest, false);
+                        if ((rc != EMFILE && rc != ENFILE) || tries >= 4000) break;
+                        usleep(tries < 100 ? 200 : 2000);
+                    }
                     if (rc && err_id) *err_id = l.id;
                 } else {
                     host_sha512_final(hs, l.src.digest);
@@ -320,6 +346,7 @@ int host_sha512_many(unsigned lanes, const std::function<int64_t()>& next, const
     }
     for (unsigned k = 0; k < 8; ++k)
         if (L[k].fd >= 0) close(L[k].fd);
+    for (size_t q = 0; q < deferred.size() && !rc; ++q) rc = one(deferred[q], get(deferred[q]));
     return rc;
 }
 

@@ -22,6 +22,47 @@ using MinHeap = std::priority_queue<double, std::vector<double>, std::greater<do
 
 } // namespace
 
+namespace {
+// the first observation stands, later ones move the estimate a quarter of the way (one odd batch does not re-plan a box)
+bool take(double& est, unsigned& count, double rate, double lo, double hi)
+{
+    if (!(rate >= lo && rate <= hi)) return false;
+    est = count == 0 ? rate : 0.75 * est + 0.25 * rate;
+    ++count;
+    return true;
+}
+// what the model calls the link is the staged pass end to end, a little under the copies' own rate: 54 GB/s of files and
+// 55 of memory where the events say 56.7 (profiles/r04_h2d_probe.txt)
+constexpr double kLinkOfDmaFiles = 54.0 / 56.7, kLinkOfDmaMem = 55.0 / 56.7;
+} // namespace
+
+bool PlanCalib::observe_dma(double bytes, double seconds)
+{
+    if (bytes < (double)(4u << 20) || seconds < 50e-6) return false;
+    return take(dma, n_dma, bytes / seconds, 2e9, 400e9);
+}
+
+bool PlanCalib::observe_fill(bool files, double bytes, double thread_seconds)
+{
+    if (bytes < (double)(4u << 20) || thread_seconds < 50e-6) return false;
+    return files ? take(fill_files, n_fill_files, bytes / thread_seconds, 0.2e9, 100e9)
+                 : take(fill_mem, n_fill_mem, bytes / thread_seconds, 0.2e9, 100e9);
+}
+
+void PlanCalib::apply(PlanModel& m) const
+{
+    if (m.gpu_link <= 0 && dma > 0) m.gpu_link = dma * (m.from_files ? kLinkOfDmaFiles : kLinkOfDmaMem);
+    if (m.fill_rate <= 0) {
+        if (m.from_files) {
+            // no file has been read yet: a box whose cores copy memory slower or faster than the model's preads by that much too
+            if (fill_files > 0) m.fill_rate = fill_files;
+            else if (fill_mem > 0) m.fill_rate = 6.5e9 * std::min(4.0, std::max(0.25, fill_mem / 9e9));
+        } else if (fill_mem > 0) {
+            m.fill_rate = fill_mem;
+        }
+    }
+}
+
 PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
 {
     PlanResult res;

@@ -33,6 +33,24 @@ struct PlanModel {
                                   // streams short enough to share a core (under a quarter of a thread's share of the host part)
 };
 
+// What THIS box does, as far as the library has seen it (round 5: the model's constants were one lease's 16-CPU quota and
+// one PCIe link; the 8-GPU node is another box).  The two constants that move most between boxes -- what an engine's
+// copy engine moves over its link and what one fill thread moves into the staging buffers -- are measured when a ctx
+// that may plan is created (a few timed copies, ~1 ms) and corrected by every staged call afterwards (HIP events of
+// the H2D copies; wall x threads of the fills); snaphash_stats_ex sets the model's prediction beside what the call took.
+// Host-only arithmetic: the CPU suite drives it through snaphash_calib_observe.
+struct PlanCalib {
+    double dma = 0;         // B/s one engine's H2D copies run at (HIP events); 0 = not measured: the model's default link
+    double fill_mem = 0;    // B/s ONE fill thread copies from caller memory into pinned staging
+    double fill_files = 0;  // B/s ONE fill thread preads from the page cache into pinned staging
+    unsigned n_dma = 0, n_fill_mem = 0, n_fill_files = 0; // observations taken
+    // an observation: bytes moved in `seconds` (link: summed event time of the copies; fill: wall x threads at it).
+    // Too small to mean anything (under 4 MiB, under 50 us) or outside what any box does: ignored (returns false).
+    bool observe_dma(double bytes, double seconds);
+    bool observe_fill(bool files, double bytes, double thread_seconds);
+    void apply(PlanModel& m) const; // fills gpu_link / fill_rate of a model that has not set them
+};
+
 struct PlanResult {
     std::vector<uint8_t> on_host; // per stream: 1 = a host thread hashes it
     unsigned host_threads = 0;    // threads the host part should run on (0 = no host part)

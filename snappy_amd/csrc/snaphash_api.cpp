@@ -91,6 +91,8 @@ double now_ms()
 
 } // namespace
 
+struct snaphash_ctx;
+
 // One engine: a device, its streams, staging buffers and kernel scratch.  A snaphash_ctx owns one
 // or several of these.
 struct DevCtx {
@@ -147,8 +149,12 @@ struct DevCtx {
     int numa_node = -1;        // -1: unknown or not applied (single-node host, SNAPHASH_FLAG_NO_NUMA)
     int staging_node = -1;     // node the first staging page was found on after allocation (diagnostic)
     int64_t fd_budget = 0;     // file descriptors a hashing call may keep open between batches (FdCache)
+    int64_t fd_call_budget = -1; // fewer than that for the call in progress (its host lanes hold descriptors too; -1 = no)
     unsigned fill_cap = 12;    // most fill threads this engine uses (the ctx divides the usable CPUs among its engines)
     unsigned fill_call_cap = 0; // fewer than that for the call in progress (a rank's share of the node's cores; 0 = no)
+    snaphash_ctx* owner = nullptr; // for what the engine measures about the box (planner.h PlanCalib)
+    double fill_thread_s = 0;   // this call: wall x threads of its staging fills ...
+    uint64_t fill_bytes = 0;    // ... and the bytes they moved
     FillPool pool;
 
     snaphash_stats stats{};
@@ -182,6 +188,8 @@ struct snaphash_ctx {
     unsigned cpus = 1;         // usable_cpus() at init: affinity mask capped by the cgroup's CPU quota
     unsigned cpus_call = 0;    // the cores THIS call may plan with (0 = cpus): a rank of a one-process-per-GPU job plans with its share
     double host_rate = 1.4e9;  // bytes/s of one host thread's SHA-512 on this box, measured at init
+    PlanCalib calib;           // the link and the fill threads of THIS box, as measured at init and by every staged call since
+    std::mutex calib_mu;       // (the engines of a multi-device ctx report from their own threads)
     uint32_t flags = 0;
     Rccl rccl;
     std::vector<uint8_t*> d_gather; // per device: n_devices * kmax * 64 bytes
@@ -454,7 +462,13 @@ int do_read_op(const Source& s, const ReadOp& op, FdCache* cache = nullptr)
     int fd = cache ? cache->fd[op.src] : -1;
     bool cached = fd >= 0;
     if (fd < 0) {
-        fd = open(s.path, O_RDONLY | O_CLOEXEC);
+        // out of descriptors: what holds them (kept descriptors of streams about to end, the host part's lanes) lets go
+        // shortly; the reference's one-file-at-a-time loop would not have failed here, so wait a bounded while
+        for (unsigned tries = 0;; ++tries) {
+            fd = open(s.path, O_RDONLY | O_CLOEXEC);
+            if (fd >= 0 || (errno != EMFILE && errno != ENFILE) || tries >= 2000) break;
+            usleep(tries < 100 ? 200 : 2000);
+        }
         if (fd < 0) err = errno;
         else if (cache && !op.to_eof && cache->held.load(std::memory_order_relaxed) < cache->budget) { // more segments will follow
             cache->fd[op.src] = fd;
@@ -500,6 +514,17 @@ void run_reads(DevCtx* c, const std::vector<Source>& src, const std::vector<Read
     unsigned cap = forced ? (unsigned)forced : std::min(c->fill_cap, from_memory ? 6u : 12u);
     if (!forced && c->fill_call_cap) cap = std::min(cap, c->fill_call_cap);
     const unsigned T = (unsigned)std::min<size_t>(cap, std::max<size_t>(1, ops.size() / 4));
+    const double t_fill0 = now_ms();
+    struct FillAccount { // what the fill threads of this box move (planner.h PlanCalib): wall x threads, bytes
+        DevCtx* c; const std::vector<ReadOp>& ops; unsigned T; double t0;
+        ~FillAccount()
+        {
+            uint64_t b = 0;
+            for (const ReadOp& op : ops) b += op.n;
+            c->fill_bytes += b;
+            c->fill_thread_s += (now_ms() - t0) * 1e-3 * T;
+        }
+    } account{c, ops, T, t_fill0};
     c->pool.parallel_for(ops.size(), T, [&](size_t i) {
         if (first_err.load(std::memory_order_relaxed)) return;
         const ReadOp& op = ops[i];
@@ -537,6 +562,8 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     rc = ensure_state(c, n, true);
     if (rc) return rc;
 
+    c->fill_thread_s = 0;
+    c->fill_bytes = 0;
     std::vector<uint64_t> done(n, 0);
     std::vector<uint32_t> active;
     active.reserve(n);
@@ -548,7 +575,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     std::atomic<int64_t> first_err_src{-1};
     std::vector<ReadOp> ops;
     const bool from_memory = src[0].mem != nullptr;
-    FdCache fds(from_memory ? 0 : n, c->fd_budget);
+    FdCache fds(from_memory ? 0 : n, c->fd_call_budget >= 0 ? std::min(c->fd_call_budget, c->fd_budget) : c->fd_budget);
     const uint64_t seg_floor = from_memory ? kMinSegmentMem : kMinSegment;
     // The batch: a job of more than a buffer is cut into about two dozen batches (32 MiB at least, a buffer at most, and
     // room for every stream's floor), each in a sub-slot of the buffers; so many are in flight that the fill runs
@@ -657,7 +684,8 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         still.insert(still.end(), skipped.begin(), skipped.end());
         still.insert(still.end(), floor_still.begin(), floor_still.end());
         active.swap(still);
-        if (getenv("SNAPHASH_TRACE_BATCHES")) {
+        static const bool trace_batches = getenv("SNAPHASH_TRACE_BATCHES") != nullptr; // (read once, not once a batch)
+        if (trace_batches) {
             uint64_t mx = 0;
             for (size_t k = 0; k < nj; ++k) mx = std::max<uint64_t>(mx, sl.h_jobs[k].nbytes);
             fprintf(stderr, "snaphash engine %d: batch %u: S %llu, %zu segments, %llu bytes, largest share %llu, %zu streams left behind\n", c->index, batch,
@@ -688,7 +716,8 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
 
     const double ts0 = now_ms();
     rc = sync_ctx(c);
-    if (getenv("SNAPHASH_TRACE_TREE"))
+    static const bool trace_tree = getenv("SNAPHASH_TRACE_TREE") != nullptr;
+    if (trace_tree)
         fprintf(stderr, "snaphash engine %d: %u batches; waiting for a slot %.1f ms, planning %.1f ms, reads %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
                 c->index, batch, t_wait, t_plan, t_read, t_launch, now_ms() - ts0);
     for (SubSlot& ss : c->sub) ss.busy = false;
@@ -704,6 +733,11 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     if (states) HIP_TRY(c, hipMemcpy(states, c->d_state, n * 64, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; ++i) c->stats.bytes_hashed += src[i].gpu_len;
     c->stats.streams = n;
+    if (c->owner) { // what this call says about the box: the copies' own rate (HIP events) and what a fill thread moved
+        std::lock_guard<std::mutex> lk(c->owner->calib_mu);
+        c->owner->calib.observe_dma((double)job_bytes, c->stats.h2d_ms * 1e-3);
+        c->owner->calib.observe_fill(!from_memory, (double)c->fill_bytes, c->fill_thread_s);
+    }
     return SNAPHASH_OK;
 }
 
@@ -860,6 +894,10 @@ PlanModel plan_model_of(const snaphash_ctx* x, bool from_files)
     m.host_threads = x->host_threads;
     m.from_files = from_files;
     m.host_rate = from_files ? x->host_rate * 0.9 : x->host_rate; // a host thread reads its file itself (pread, then hash)
+    {
+        std::lock_guard<std::mutex> lk(const_cast<snaphash_ctx*>(x)->calib_mu);
+        x->calib.apply(m); // this box's link and fill rates where they have been measured (planner.h PlanCalib)
+    }
     return m;
 }
 
@@ -906,12 +944,22 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     for (Source& s : src) s.gpu_len = s.len;
     std::vector<uint8_t> on_host(n, 0);
     unsigned plan_threads = 0;
+    const double t_hash0 = now_ms();
+    struct HashClock { // snaphash_stats_ex.hash_ms on every way out
+        snaphash_ctx* x; double t0;
+        ~HashClock() { x->ex.hash_ms = now_ms() - t0; }
+    } hash_clock{x, t_hash0};
     if (!x->gpu_only) {
         std::vector<uint64_t> lens(n);
         for (size_t i = 0; i < n; ++i) lens[i] = src[i].len;
         PlanResult plan = plan_streams(lens.data(), n, plan_model_of(x, src[0].path != nullptr));
         on_host.swap(plan.on_host);
         plan_threads = plan.host_threads;
+        // the prediction, to be read beside what the call then takes (gpu_ms, host_ms below)
+        x->ex.planned_gpu_ms = plan.gpu_seconds * 1e3;
+        x->ex.planned_host_ms = plan.host_seconds * 1e3;
+        x->ex.planned_threads = plan.host_threads;
+        x->ex.plan_ms = now_ms() - t_hash0;
     }
 
     // GPU part: LPT over the devices by SHA-512 block count (deterministic)
@@ -942,7 +990,10 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     struct DevJob { std::vector<Source> sub; std::vector<uint8_t> dig; int rc = 0, err_no = 0; int64_t err_src = -1; };
     std::vector<DevJob> job(nd);
     const bool keep_on_device = nd > 1 || (x->flags & SNAPHASH_FLAG_FORCE_GATHER); // digests stay in HBM for the gather
+    std::vector<double> gbusy(nd, 0.0);
     auto run_dev = [&](size_t d) {
+        const double tg0 = now_ms();
+        struct Busy { double& out; double t0; ~Busy() { out = now_ms() - t0; } } busy{gbusy[d], tg0};
         DevJob& J = job[d];
         J.sub.reserve(member[d].size());
         for (uint32_t g : member[d]) J.sub.push_back(src[g]);
@@ -954,7 +1005,8 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     std::atomic<size_t> hnext{0};
     std::atomic<int> herr{0};
     std::atomic<int64_t> herr_src{-1};
-    const unsigned nh = hidx.empty() ? 0u : std::max(1u, std::min<unsigned>(plan_threads, (unsigned)hidx.size()));
+    unsigned nh = hidx.empty() ? 0u : std::max(1u, std::min<unsigned>(plan_threads, (unsigned)hidx.size()));
+    const bool gpu_part = !gidx.empty();
     const bool spare_cores = 2u * nh <= (x->cpus_call ? x->cpus_call : x->cpus); // a long file stream may take a reader thread beside its hasher (hostsha.h)
     std::vector<double> hbusy(std::max(1u, nh), 0.0);
     std::stable_sort(hidx.begin(), hidx.end(), [&](uint32_t a, uint32_t b) { return src[a].len > src[b].len; });
@@ -966,7 +1018,28 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     const uint64_t alone_from = nh ? host_bytes_planned / nh / 4 : 0;
     size_t n_lane_streams = 0;
     for (uint32_t g : hidx) n_lane_streams += src[g].len < alone_from || alone_from == 0;
-    const unsigned host_lanes = nh ? (unsigned)std::min<size_t>(8, (n_lane_streams + nh - 1) / nh) : 1u;
+    unsigned host_lanes = nh ? (unsigned)std::min<size_t>(8, (n_lane_streams + nh - 1) / nh) : 1u;
+    // ONE descriptor budget for the call: a host thread holds a descriptor per lane, the staging fill keeps a
+    // file's descriptor between the batches it appears in (FdCache) -- on a host of 128 cores that is 1 000-2 000 lanes'
+    // worth where RLIMIT_NOFILE may be 1 024 (SNAPHASH_FLAG_KEEP_RLIMIT, a low hard limit), and the reference's loop
+    // holds ONE.  The soft limit less a reserve for the application is divided: the lanes take what they need up to half
+    // of it beside a GPU part (all of it alone) -- fewer lanes per thread, then fewer threads -- the kept descriptors get
+    // the rest.  An open that still meets EMFILE waits for a descriptor (do_read_op, host_sha512_many).
+    for (auto& d : x->dev) d->fd_call_budget = -1;
+    if (src[0].path != nullptr) {
+        struct rlimit rl;
+        int64_t soft = 1024;
+        if (getrlimit(RLIMIT_NOFILE, &rl) == 0) soft = rl.rlim_cur == RLIM_INFINITY ? 65536 : (int64_t)rl.rlim_cur;
+        const int64_t total = std::max<int64_t>(2, soft - std::min<int64_t>(512, soft / 2));
+        int64_t lanes_fds = (int64_t)nh * host_lanes;
+        const int64_t lanes_cap = gpu_part ? std::max<int64_t>(1, total / 2) : total;
+        if (lanes_fds > lanes_cap) {
+            if ((int64_t)nh > lanes_cap) nh = (unsigned)lanes_cap;
+            host_lanes = (unsigned)std::max<int64_t>(1, lanes_cap / nh);
+            lanes_fds = (int64_t)nh * host_lanes;
+        }
+        for (auto& d : x->dev) d->fd_call_budget = std::max<int64_t>(0, (total - lanes_fds) / (int64_t)nd);
+    }
     auto run_host = [&](unsigned t) {
         const double t0 = now_ms();
         int64_t bad = -1;
@@ -997,7 +1070,6 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
 
     // A call whose streams all went to the host has no GPU part: the calling thread is the first of the pool (the literal
     // one-file helpers.Sha512sum starts no thread at all).  Otherwise the caller drives the engine(s).
-    const bool gpu_part = !gidx.empty();
     ThreadJoiner th, dth;
     try {
         for (unsigned t = gpu_part ? 0u : 1u; t < nh; ++t) th.spawn(run_host, t);
@@ -1018,6 +1090,8 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     for (uint32_t g : hidx) { x->ex.host_bytes += src[g].len; }
     x->ex.host_streams = hidx.size();
     for (double b : hbusy) x->ex.host_ms = std::max(x->ex.host_ms, b);
+    for (double b : gbusy) x->ex.gpu_ms = std::max(x->ex.gpu_ms, b);
+    x->ex.host_threads_run = nh;
 
     // first error (lowest walk index) fails the call, as the reference's loop would (build.go:242-244)
     int64_t bad = -1;
@@ -1191,6 +1265,52 @@ static void destroy_dev(DevCtx* c)
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
+// The two constants of the planner's model that differ most from box to box, measured where the ctx is made (~1-2 ms):
+// what the first engine's copy engine moves over its link -- two timed H2D copies out of pinned memory, a quarter and a
+// whole of 8 MiB, so that what a copy costs whatever its size drops out of the difference -- and what one thread copies
+// from ordinary memory into pinned staging.  Every staged call corrects both afterwards (hash_sources).  Never fatal: a
+// probe that cannot run leaves the model's defaults in place.
+static void calibrate_at_init(snaphash_ctx* x)
+{
+    if (getenv("SNAPHASH_NO_CALIBRATION")) return;
+    DevCtx* c = x->d0();
+    if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return; }
+    constexpr uint64_t kProbe = 8u << 20;
+    if (c->staging < kProbe) return; // (a ctx made with toy staging buffers, as tests do, is not worth a probe)
+    if (ensure_slots(c, 1, kProbe) != SNAPHASH_OK) { c->last_error.clear(); (void)hipGetLastError(); return; }
+    Slot& s = c->slot[0];
+    const size_t big = (size_t)kProbe, small = big / 4;
+    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    bool ok = true;
+    for (hipEvent_t& ev : e) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    if (ok) {
+        ok = hipMemcpyAsync(s.d_buf, s.h_buf, small, hipMemcpyHostToDevice, c->copy_stream) == hipSuccess; // warm: the first copy of a stream pays for its set-up
+        ok = ok && hipEventRecord(e[0], c->copy_stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(s.d_buf, s.h_buf, small, hipMemcpyHostToDevice, c->copy_stream) == hipSuccess;
+        ok = ok && hipEventRecord(e[1], c->copy_stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(s.d_buf, s.h_buf, big, hipMemcpyHostToDevice, c->copy_stream) == hipSuccess;
+        ok = ok && hipEventRecord(e[2], c->copy_stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(c->copy_stream) == hipSuccess;
+        float t_small = 0, t_big = 0;
+        ok = ok && hipEventElapsedTime(&t_small, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&t_big, e[1], e[2]) == hipSuccess;
+        if (ok && t_big > t_small) x->calib.observe_dma((double)(big - small), (double)(t_big - t_small) * 1e-3);
+    }
+    for (hipEvent_t ev : e) if (ev) (void)hipEventDestroy(ev);
+    if (!ok) (void)hipGetLastError();
+    {
+        std::vector<uint8_t> from(4u << 20, 0x3c);
+        copy_to_staging(s.h_buf, from.data(), from.size()); // warm (page tables of both sides)
+        double best = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            const double t0 = now_ms();
+            copy_to_staging(s.h_buf, from.data(), from.size());
+            const double dt = (now_ms() - t0) * 1e-3;
+            if (dt > 0 && (best == 0 || dt < best)) best = dt;
+        }
+        if (best > 0) x->calib.observe_fill(false, (double)from.size(), best);
+    }
+}
+
 int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
 try {
     if (!out) return SNAPHASH_EINVAL;
@@ -1348,6 +1468,8 @@ try {
             if (!mine.empty()) c->pool.configure(256, mine);
         }
     }
+    for (auto& d : x->dev) d->owner = x.get();
+    if (!x->gpu_only) calibrate_at_init(x.get()); // a ctx that may plan measures the box it plans for (planner.h PlanCalib)
     *out = x.release();
     return SNAPHASH_OK;
 } catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
@@ -1485,7 +1607,8 @@ static int tree_impl(snaphash_ctx* x, const char* build_dir, const char* data_ta
     const uint8_t* arch = data_tar ? dig.data() : archive_digest;
     const uint8_t* files = data_tar ? dig.data() + 64 : dig.data();
     rc = emit_yaml(recs, arch, files, yaml);
-    if (getenv("SNAPHASH_TRACE_TREE"))
+    static const bool trace_tree = getenv("SNAPHASH_TRACE_TREE") != nullptr;
+    if (trace_tree)
         fprintf(stderr, "snaphash tree: walk %.1f ms (%zu records), hash %.1f ms (%zu streams), yaml %.1f ms (%zu bytes)\n", tw1 - tw0,
                 recs.size(), th1 - th0, paths.size(), now_ms() - th1, yaml.size());
     return rc;
@@ -1642,6 +1765,7 @@ struct snaphash_shard {
     std::vector<const char*> my_paths;
     std::vector<int64_t> my_sizes;
     uint32_t rank = 0, world = 1;
+    uint32_t local_ranks = 0; // ranks that share this node's cores, as the caller said (0 = not said)
     size_t rows = 1;
     uint64_t my_bytes = 0;
 };
@@ -1686,7 +1810,8 @@ try {
             sh->my_sizes.push_back(i == 0 ? -1 : sh->all_sizes[i]); // the archive's length is taken when it is read, like snaphash_tree
             sh->my_bytes += lens[i];
         }
-    if (getenv("SNAPHASH_TRACE_TREE"))
+    static const bool trace_tree = getenv("SNAPHASH_TRACE_TREE") != nullptr;
+    if (trace_tree)
         fprintf(stderr, "snaphash shard plan: walk %.2f ms (%zu records), names + lists + LPT over %u ranks %.2f ms\n", tp1 - tp0, sh->recs.size(), world, now_ms() - tp1);
     *out = sh.release();
     return SNAPHASH_OK;
@@ -1708,9 +1833,23 @@ try {
     // The ranks of a node share its cores: this process sees the whole job's allowance (affinity mask, cgroup quota), and
     // eight ranks that each planned host threads for all of it would be eight times too many.  A rank plans with its
     // share -- the allowance over the ranks that can be on this node (at most one per visible GPU).
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
-    const unsigned ranks_here = std::max(1u, std::min<unsigned>(sh->world, (unsigned)ndev));
+    // How many that is: what the caller said (snaphash_shard_set_local_ranks), else what the launcher says
+    // (LOCAL_WORLD_SIZE of torch.distributed.run, Open MPI's OMPI_COMM_WORLD_LOCAL_SIZE), and only then a guess from the
+    // visible GPUs -- a launcher that shows every rank ONE device would make that guess 1, and every rank would plan for
+    // the whole node.
+    unsigned ranks_here = sh->local_ranks;
+    for (const char* name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS"}) {
+        if (ranks_here) break;
+        const char* e = getenv(name);
+        const long v = e ? strtol(e, nullptr, 10) : 0;
+        if (v >= 1 && v <= 4096) ranks_here = (unsigned)v;
+    }
+    if (!ranks_here) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
+        ranks_here = std::min<unsigned>(sh->world, (unsigned)ndev);
+    }
+    ranks_here = std::max(1u, std::min(ranks_here, sh->world));
     struct Share {
         snaphash_ctx* x;
         ~Share()
@@ -1754,11 +1893,46 @@ try {
 
 void snaphash_shard_free(snaphash_shard* sh) { delete sh; }
 
+int snaphash_shard_set_local_ranks(snaphash_shard* sh, uint32_t ranks_on_this_node)
+{
+    if (!sh || ranks_on_this_node > sh->world) return SNAPHASH_EINVAL;
+    sh->local_ranks = ranks_on_this_node;
+    return SNAPHASH_OK;
+}
+
+// FNV-1a over what every rank must agree on before the collective: the records as walked (name, mode, size), the
+// archive's size, the world and who hashes which stream into which row
+uint64_t snaphash_shard_fingerprint(const snaphash_shard* sh)
+{
+    if (!sh) return 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const void* p, size_t n) {
+        const uint8_t* b = (const uint8_t*)p;
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    auto mix64 = [&mix](uint64_t v) { mix(&v, 8); };
+    mix64(sh->world);
+    mix64(sh->rows);
+    mix64(sh->recs.size());
+    for (const Record& r : sh->recs) {
+        mix(r.name.data(), r.name.size() + 1);
+        mix64(((uint64_t)r.st_mode << 1) | (r.is_regular ? 1u : 0u));
+        mix64(r.is_regular ? (uint64_t)r.size : 0);
+    }
+    for (size_t i = 0; i < sh->all_sizes.size(); ++i) {
+        mix64((uint64_t)sh->all_sizes[i]);
+        mix64(((uint64_t)(uint32_t)sh->shard_of[i] << 32) | sh->row_of[i]);
+    }
+    return h ? h : 1;
+}
+
 // ---- ABI 4: the plan of a call (host-only) ---------------------------------------------------------------------
 int snaphash_plan_streams(const uint64_t* lens, size_t n, snaphash_plan_model* pm, uint8_t* on_host)
 try {
-    if (!pm || pm->struct_size < sizeof(snaphash_plan_model) || (n && !lens)) return SNAPHASH_EINVAL;
+    constexpr uint32_t kAbi4Size = (uint32_t)offsetof(snaphash_plan_model, fill_rate);
+    if (!pm || pm->struct_size < kAbi4Size || (n && !lens)) return SNAPHASH_EINVAL;
     PlanModel m;
+    if (pm->struct_size >= sizeof(snaphash_plan_model) && pm->fill_rate > 0) m.fill_rate = pm->fill_rate;
     m.n_devices = pm->n_devices ? pm->n_devices : 1;
     m.cpus = pm->cpus ? pm->cpus : usable_cpus();
     m.from_files = pm->from_files != 0;
@@ -1779,6 +1953,75 @@ try {
     return SNAPHASH_OK;
 } catch (...) {
     return SNAPHASH_ENOMEM;
+}
+
+int snaphash_get_plan_model(const snaphash_ctx* x, int from_files, snaphash_plan_model* pm)
+try {
+    constexpr uint32_t kAbi4Size = (uint32_t)offsetof(snaphash_plan_model, fill_rate);
+    if (!x || !pm || pm->struct_size < kAbi4Size) return SNAPHASH_EINVAL;
+    const uint32_t have = std::min<uint32_t>(pm->struct_size, (uint32_t)sizeof(snaphash_plan_model));
+    const PlanModel m = plan_model_of(x, from_files != 0);
+    snaphash_plan_model v;
+    memset(&v, 0, sizeof v);
+    v.struct_size = have;
+    v.n_devices = m.n_devices;
+    v.cpus = m.cpus;
+    v.fill_threads = m.fill_threads;
+    v.host_threads = m.host_threads;
+    v.from_files = m.from_files ? 1u : 0u;
+    v.host_rate = m.host_rate;
+    v.gpu_stream_rate = m.gpu_pair_rate;
+    v.gpu_link = m.gpu_link > 0 ? m.gpu_link : (m.from_files ? 54e9 : 55e9);
+    v.gpu_latency = m.gpu_latency;
+    v.host_lane_gain_pct = (uint32_t)(m.host_lane_gain * 100.0 + 0.5);
+    v.fill_rate = m.fill_rate > 0 ? m.fill_rate : (m.from_files ? 6.5e9 : 9e9);
+    memcpy(pm, &v, have);
+    return SNAPHASH_OK;
+} catch (...) {
+    return SNAPHASH_ENOMEM;
+}
+
+static PlanCalib calib_of(const snaphash_plan_calib* c)
+{
+    PlanCalib k;
+    k.dma = c->dma; k.fill_mem = c->fill_mem; k.fill_files = c->fill_files;
+    k.n_dma = c->n_dma; k.n_fill_mem = c->n_fill_mem; k.n_fill_files = c->n_fill_files;
+    return k;
+}
+static void calib_to(const PlanCalib& k, snaphash_plan_calib* c)
+{
+    c->dma = k.dma; c->fill_mem = k.fill_mem; c->fill_files = k.fill_files;
+    c->n_dma = k.n_dma; c->n_fill_mem = k.n_fill_mem; c->n_fill_files = k.n_fill_files;
+}
+
+int snaphash_calib_observe(snaphash_plan_calib* c, int what, double bytes, double seconds)
+{
+    if (!c || c->struct_size < sizeof(snaphash_plan_calib) || what < 0 || what > 2) return SNAPHASH_EINVAL;
+    PlanCalib k = calib_of(c);
+    const bool took = what == 0 ? k.observe_dma(bytes, seconds) : k.observe_fill(what == 2, bytes, seconds);
+    calib_to(k, c);
+    return took ? 1 : 0;
+}
+
+int snaphash_calib_apply(const snaphash_plan_calib* c, snaphash_plan_model* pm)
+{
+    if (!c || c->struct_size < sizeof(snaphash_plan_calib) || !pm || pm->struct_size < sizeof(snaphash_plan_model)) return SNAPHASH_EINVAL;
+    PlanModel m;
+    m.from_files = pm->from_files != 0;
+    m.gpu_link = pm->gpu_link;
+    m.fill_rate = pm->fill_rate;
+    calib_of(c).apply(m);
+    pm->gpu_link = m.gpu_link;
+    pm->fill_rate = m.fill_rate;
+    return SNAPHASH_OK;
+}
+
+int snaphash_get_calib(const snaphash_ctx* x, snaphash_plan_calib* out)
+{
+    if (!x || !out || out->struct_size < sizeof(snaphash_plan_calib)) return SNAPHASH_EINVAL;
+    std::lock_guard<std::mutex> lk(const_cast<snaphash_ctx*>(x)->calib_mu);
+    calib_to(x->calib, out);
+    return SNAPHASH_OK;
 }
 
 uint32_t snaphash_usable_cpus(void) { return usable_cpus(); }
@@ -2480,10 +2723,13 @@ void snaphash_get_stats(const snaphash_ctx* c, snaphash_stats* out)
 
 int snaphash_get_stats_ex(const snaphash_ctx* c, snaphash_stats_ex* out)
 try {
-    if (!c || !out || out->struct_size < sizeof(snaphash_stats_ex)) return SNAPHASH_EINVAL;
-    *out = c->ex;
-    out->struct_size = sizeof(snaphash_stats_ex);
-    out->n_devices = (uint32_t)c->dev.size();
+    constexpr uint32_t kAbi4Size = (uint32_t)offsetof(snaphash_stats_ex, planned_gpu_ms);
+    if (!c || !out || out->struct_size < kAbi4Size) return SNAPHASH_EINVAL;
+    const uint32_t have = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(snaphash_stats_ex));
+    snaphash_stats_ex v = c->ex;
+    v.struct_size = have;
+    v.n_devices = (uint32_t)c->dev.size();
+    memcpy(out, &v, have);
     return SNAPHASH_OK;
 } catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
     return SNAPHASH_ENOMEM;
@@ -2500,6 +2746,10 @@ static void engine_footprint(const snaphash_ctx* x, size_t i, uint64_t* pinned, 
         if (s.d_buf) h += s.cap + 256;
         p += s.jobs_cap * sizeof(Job);
         h += s.jobs_cap * sizeof(Job);
+    }
+    for (const SubSlot& q : d->sub) { // the job arrays of the batches in flight (pinned and HBM twins)
+        p += q.jobs_cap * sizeof(Job);
+        h += q.jobs_cap * sizeof(Job);
     }
     p += d->jobs_cap * sizeof(Job) + d->chunks_cap * sizeof(CmpChunk);
     h += d->jobs_cap * sizeof(Job) + d->chunks_cap * sizeof(CmpChunk) + d->state_cap * 64 + d->digests_cap * 64 + d->equal_cap;

@@ -57,37 +57,85 @@ class ShardedTree:
         yaml = st.emit(st.gather(slab))      # all ranks' slabs -> hashes.yaml
     """
 
-    def __init__(self, build_dir, data_tar, rank, world):
+    def __init__(self, build_dir, data_tar, rank, world, local_ranks=0):
+        """local_ranks: how many of the `world` ranks share THIS node's cores (0 = the launcher's LOCAL_WORLD_SIZE, else a
+        guess from the visible GPUs): a rank plans host threads and fill threads for its share of them."""
         import ctypes
         h = ctypes.c_void_p()
         rc = _lib.lib().snaphash_shard_plan(build_dir.encode(), data_tar.encode(), rank, world, ctypes.byref(h))
-        if rc:
-            raise _lib.SnaphashError(rc, build_dir)
-        self._h = h
+        self._h = h if not rc else None
+        self._plan_rc = rc
         self.rank, self.world = rank, world
+        self.rows = self.count = self.streams = self.bytes = 0
+        self.fingerprint = 0
+        self._hash_rc = 0
+        if rc:
+            if world == 1 or rc == _lib.EINVAL:  # (a bad argument is the caller's bug, not a rank's misfortune)
+                raise _lib.SnaphashError(rc, build_dir)
+            return  # with other ranks about: reported at gather(), where every rank learns of it (see agree())
         L = _lib.lib()
+        if local_ranks:
+            L.snaphash_shard_set_local_ranks(h, local_ranks)
         self.rows = L.snaphash_shard_rows(h)
         self.count = L.snaphash_shard_count(h)
         self.streams = L.snaphash_shard_streams(h)
         self.bytes = L.snaphash_shard_bytes(h)
+        self.fingerprint = L.snaphash_shard_fingerprint(h)
 
     def paths(self):
         L = _lib.lib()
         return [L.snaphash_shard_path(self._h, k).decode() for k in range(self.count)]
 
     def hash(self, ctx, out=None):
-        """Hashes this rank's members on ctx; returns the slab as a numpy [rows, 64] uint8 array (out: reuse one)."""
+        """Hashes this rank's members on ctx; returns the slab as a numpy [rows, 64] uint8 array (out: reuse one).
+        With other ranks about, a failure here is not raised here: the rank must still reach the collective, where
+        every rank learns of it (agree)."""
+        if self._plan_rc:
+            return np.zeros((max(self.rows, 1), 64), dtype=np.uint8)
         slab = out if out is not None else np.zeros((self.rows, 64), dtype=np.uint8)
-        ctx._check(_lib.lib().snaphash_shard_hash(ctx._h, self._h, slab.ctypes.data))
+        rc = _lib.lib().snaphash_shard_hash(ctx._h, self._h, slab.ctypes.data)
+        if rc and self.world == 1:
+            ctx._check(rc)
+        self._hash_rc = rc
+        self._hash_err = (_lib.lib().snaphash_last_error(ctx._h) or b"").decode(errors="replace") if rc else ""
         return slab
+
+    def agree(self, device=None, group=None):
+        """Before the all-gather: every rank's (plan rc, hash rc, streams, rows, fingerprint of the plan), all-gathered.
+        Raises on EVERY rank if any rank failed or walked another tree -- the reference's serial loop returns its first
+        error (snappy/build.go:242-244); a rank that left alone would leave the others blocked in the collective until
+        the process group times out, and slabs of different plans would be gathered into the wrong rows.
+        A caller that drives the C API directly owes the same check (snaphash_shard_fingerprint)."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return
+        fp = int(self.fingerprint)
+        mine = torch.tensor([self._plan_rc, self._hash_rc, self.streams, self.rows, fp & 0x7fffffff, (fp >> 31) & 0x7fffffff, fp >> 62],
+                            dtype=torch.int64, device=device or "cpu")
+        every = torch.empty((self.world, mine.numel()), dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(every.view(-1), mine, group=group)
+        every = every.cpu().tolist()
+        for r, row in enumerate(every):
+            if row[0] or row[1]:
+                what = "snaphash_shard_plan" if row[0] else "snaphash_shard_hash"
+                detail = (": " + self._hash_err) if r == self.rank and row[1] and getattr(self, "_hash_err", "") else ""
+                raise _lib.SnaphashError(row[0] or row[1], "rank %d failed in %s%s (every rank raises: nobody is left in the collective)" % (r, what, detail))
+        for r, row in enumerate(every):
+            if row[2:] != every[0][2:]:
+                raise _lib.SnaphashError(_lib.EMISMATCH, "rank %d walked another tree than rank 0 (%d streams / %d rows / plan %x against %d / %d / %x): "
+                                         "the tree changed between the ranks' walks" % (r, row[2], row[3], row[4] | row[5] << 31 | row[6] << 62,
+                                                                                          every[0][2], every[0][3], every[0][4] | every[0][5] << 31 | every[0][6] << 62))
 
     def gather(self, slab, device=None, group=None):
         """All ranks' slabs, rank-major [world * rows, 64], on the host.  device: where the collective runs ("cuda" for
-        RCCL; None = CPU tensors over gloo)."""
+        RCCL; None = CPU tensors over gloo).  The ranks first agree that they hold the same plan and that nobody failed
+        (agree): 56 bytes a rank in front of the slabs."""
         import torch
         import torch.distributed as dist
         if self.world == 1:
             return slab
+        self.agree(device=device, group=group)
         t = torch.from_numpy(slab)
         if device is not None:
             t = t.to(device, non_blocking=False)

@@ -182,3 +182,95 @@ def test_sharded_tree_edge_shapes_without_a_collective(world, built_lib, oracle,
     (shapes / "a-b").write_bytes(b"x")              # Walk order: a, a/..., a-b -- not a global sort of the paths
     (shapes / "DEBIANfoo").write_bytes(b"skipped")  # string prefix, not path component (build.go:229)
     run(str(shapes), str(tar))
+
+
+def _disagree_worker(rank, world, port, builds, tars, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        import hashlib
+        from snappy_amd import _lib
+        from snappy_amd.sharded import ShardedTree
+        try:
+            with ShardedTree(builds[rank], tars[rank], rank, world) as st:
+                slab = np.zeros((max(st.rows, 1), 64), dtype=np.uint8)
+                for k, p in enumerate(st.paths()):
+                    slab[k] = np.frombuffer(hashlib.sha512(open(p, "rb").read()).digest(), dtype=np.uint8)
+                st.emit(st.gather(slab))
+            q.put((rank, "no error", 0))
+        except _lib.SnaphashError as e:
+            q.put((rank, str(e), e.code))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["another tree", "one rank's plan fails"])
+def test_ranks_that_disagree_all_raise_before_the_gather(case, built_lib, tmp_path):
+    """a tree that changed between the ranks' walks, or a rank that failed, must not end in mismatched slabs
+    or in ranks blocked in the collective: ShardedTree.gather first all-gathers (rc, streams, rows, fingerprint of the
+    plan) and EVERY rank raises -- as the reference's serial loop returns its first error (snappy/build.go:242-244)."""
+    import shutil
+    import trees
+    from snappy_amd import _lib
+    build, tar = trees.make_synthetic_tree(str(tmp_path / "a"), [100, 2000, 30000, 7, 512])
+    other = str(tmp_path / "b" / "build")
+    shutil.copytree(build, other)
+    if case == "another tree":
+        open(os.path.join(other, "d0000", "f000001.bin"), "ab").write(b"one more byte")  # same names, another size
+        builds, tars = [build, other], [tar, tar]
+    else:
+        builds, tars = [build, build], [tar, tar + ".gone"]  # rank 1: build.go:222's missing archive
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_disagree_worker, args=(r, 2, port, builds, tars, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, msg, code in res:
+        assert code == (_lib.EMISMATCH if case == "another tree" else _lib.EIO), (rank, msg)
+    assert ("another tree" in res[0][1]) if case == "another tree" else ("rank 1 failed in snaphash_shard_plan" in res[0][1])
+
+
+def test_shard_fingerprint_and_local_ranks(built_lib, tmp_path):
+    import trees
+    from snappy_amd import _lib
+    from snappy_amd.sharded import ShardedTree
+    build, tar = trees.make_synthetic_tree(str(tmp_path), [100, 2000, 30000, 7, 512])
+    with ShardedTree(build, tar, 0, 2) as a, ShardedTree(build, tar, 1, 2, local_ranks=2) as b, ShardedTree(build, tar, 0, 3) as c:
+        assert a.fingerprint == b.fingerprint != 0        # the same plan on every rank
+        assert c.fingerprint != a.fingerprint             # another world is another plan
+        assert _lib.lib().snaphash_shard_set_local_ranks(a._h, 3) == _lib.EINVAL  # more ranks on the node than in the job
+        assert _lib.lib().snaphash_shard_set_local_ranks(a._h, 0) == 0
+    os.chmod(os.path.join(build, "d0000", "f000000.bin"), 0o600)
+    with ShardedTree(build, tar, 0, 2) as d:
+        assert d.fingerprint != a.fingerprint             # a mode is part of what hashes.yaml says
+
+
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_gpus():
+    """`python3 bench.py --gpus N` with no launcher around it starts its N ranks itself, as child
+    processes, before the parent has imported torch or the library.  Here (no GPU) every rank refuses to run; what is
+    checked is the launcher: the parent relays the failure, ends the other ranks, exits non-zero and prints no JSON line.
+    (On the GPU box the same command prints the line: profiles/r05_bench_2ranks_same_gpu.json.)"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run the benchmark")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, env=env)
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode != 0 and r.stdout.strip() == b""
+    assert "the other ranks were ended" in err and "no CPU fallback exists" in err, err[-600:]
+    # the parent itself never loaded torch: it is the ranks that say so
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def self_launch("):src.index("def main(")]
+    assert "import torch" not in body and "snappy_amd" not in body
+    head = src[src.index("def main("):src.index("sys.exit(self_launch(args))")]
+    assert "import torch" not in head and "snappy_amd" not in head

@@ -23,6 +23,7 @@ def _ragged_sizes(n, seed, top=1 << 20):
     return s
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_two_engines_behind_one_ctx_golden_and_oracle(built_lib, oracle, tmp_path):
     """Device list {0, 0}: two engines (own streams, staging buffers, host threads) on the one GPU of
     this box.  The library LPT-shards the file list, hashes both shards concurrently and gathers the
@@ -50,6 +51,7 @@ def test_two_engines_behind_one_ctx_golden_and_oracle(built_lib, oracle, tmp_pat
         assert [d.hex() for d in c.sha512_files(paths)] == [oracle.sha512sum(p) for p in paths]
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_all_visible_devices_and_rccl_gather(built_lib, oracle):
     """Device list {-1}: every visible GPU.  On a 1-GPU box that is one engine (no gather); on a node it
     is the RCCL all-gather with the per-device copies as its parity check (FLAG_CHECK_GATHER)."""
@@ -65,6 +67,7 @@ def test_all_visible_devices_and_rccl_gather(built_lib, oracle):
     assert got == [oracle.sha512(b) for b in bufs]
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_rccl_gather_path_with_one_rank(built_lib, oracle):
     """FLAG_FORCE_GATHER: the digests stay in HBM and go through the library's single-process RCCL path
     (dlopen, ncclCommInitAll, grouped ncclAllGather, D2H of the gathered slab) with one rank, checked against
@@ -168,6 +171,7 @@ def test_verify_needs_an_archive_digest_when_given_an_archive(built_lib, tmp_pat
         assert c.verify(build, short, tar) == (6, "archive-sha512")
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_hybrid_scheduling_is_bit_exact(built_lib, oracle):
     """host_threads > 0: the few streams whose single-stream GPU time would set the makespan are hashed
     by the library's own host SHA-512 (never the oracle) concurrently with the GPU batch.
@@ -289,6 +293,7 @@ def test_distinct_contexts_on_concurrent_threads(built_lib, oracle, tmp_path):
     assert not any(t.is_alive() for t in th)
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_contexts_release_their_device_memory(built_lib, tmp_path):
     """Every allocation a ctx makes lazily (staging slots, deflate scratch incl. the 1 GiB token scratch of the default
     staging size, gather buffers, pinned buffers) goes back on snaphash_destroy: ten create / use / destroy cycles
@@ -314,6 +319,7 @@ def test_contexts_release_their_device_memory(built_lib, tmp_path):
     assert free0 - free1 < (64 << 20), (free0, free1)  # a leak of any per-ctx buffer would be hundreds of MiB per cycle
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_default_configuration_plans_every_call(built_lib, oracle, tmp_path):
     """snaphash_init(NULL) / flags 0 (ABI 4): every call is planned (planner.cpp).  The package's own archive next to its
     tree (snappy/build.go:222 -- ONE stream, 44 MB/s on the GPU against 1.4 GB/s on a host core) is hashed on a host
@@ -371,6 +377,7 @@ def test_default_configuration_plans_every_call(built_lib, oracle, tmp_path):
     assert t_default < t_gpu_only / 3  # 96 MiB alone on the GPU: ~2.2 s
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_default_configuration_through_tree_verify_and_the_producer(built_lib, oracle, tmp_path):
     """What a cgo caller gets from snaphash_init(NULL): the tree, verify and tar_create parity checks once more with
     flags = 0 (the rest of the suite keeps every byte on the GPU).  A tree large enough that the kernels and the
@@ -408,6 +415,7 @@ def test_default_configuration_through_tree_verify_and_the_producer(built_lib, o
         assert c.tree(build, tar) == want
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_eight_engines_in_one_process(built_lib, oracle):
     """Row e's in-library form as an 8-GPU node will run it, rehearsed on the one GPU this pool gives a test: devices =
     {0} x 8 (eight engines, copy gather: RCCL needs distinct devices) over BASELINE config 2's own list -- 10 001 x 1 MiB,
@@ -476,6 +484,7 @@ def test_eight_engines_in_one_process(built_lib, oracle):
           (n, t8 * 1e3, t1 * 1e3, sum(e["pinned_bytes"] for e in infos) / 2**30, hbm / 2**30, [len(s) for s in cpus]))
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_no_stream_is_left_for_the_end(built_lib):
     """5 000 equal streams through batches that hold 4 096 floors: every batch must serve a fair rotation -- the streams a
     batch had no room for go first in the next one -- so that no stream's share ever grows beyond the floor.  Rounds 1-3
@@ -512,6 +521,7 @@ def test_no_stream_is_left_for_the_end(built_lib):
     assert int(batches[-1][5]) == 0
 
 
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
 def test_descriptor_budget_smaller_than_the_tree(built_lib, oracle, tmp_path):
     """The engine keeps a file's descriptor between the batches the file appears in (FdCache) only within what
     RLIMIT_NOFILE leaves: with a budget far below the number of files the rest is opened segment by segment, as round 3

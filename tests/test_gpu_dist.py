@@ -49,6 +49,7 @@ def _worker(rank, world, port, sizes, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.kernels_only("the HBM-resident entry point never plans")
 def test_two_ranks_shard_hash_gather(oracle):
     import torch.multiprocessing as mp
     from snappy_amd import synthetic
@@ -69,7 +70,7 @@ def test_two_ranks_shard_hash_gather(oracle):
         assert blob == want, rank
 
 
-def _tree_worker(rank, world, port, build, tar, q):
+def _tree_worker(rank, world, port, build, tar, q, planned):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -79,7 +80,7 @@ def _tree_worker(rank, world, port, build, tar, q):
     try:
         from snappy_amd import Context, _lib
         from snappy_amd.sharded import ShardedTree
-        with Context(device=0, flags=_lib.FLAG_GPU_ONLY) as ctx, ShardedTree(build, tar, rank, world) as st:
+        with Context(device=0, flags=0 if planned else _lib.FLAG_GPU_ONLY) as ctx, ShardedTree(build, tar, rank, world, local_ranks=world) as st:
             slab = st.hash(ctx)
             ex = ctx.stats_ex()
             y = st.emit(st.gather(slab))
@@ -88,9 +89,10 @@ def _tree_worker(rank, world, port, build, tar, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_tree_to_hashes_yaml(oracle, tmp_path):
+def test_two_ranks_tree_to_hashes_yaml(oracle, tmp_path, snaphash_mode):
     """The whole pass as bench.py --gpus N times it (ABI 4 snaphash_shard_*): two ranks, each its LPT share of ONE on-disk
-    tree through the HIP kernels, slabs gathered, hashes.yaml on every rank byte-identical to the oracle's."""
+    tree through the HIP kernels (gpu_only) or as each rank's library plans its share (planned: a rank plans with ITS
+    share of the node's cores), slabs gathered, hashes.yaml on every rank byte-identical to the oracle's."""
     import torch.multiprocessing as mp
     import trees
     rng = np.random.default_rng(21)
@@ -102,7 +104,7 @@ def test_two_ranks_tree_to_hashes_yaml(oracle, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tree_worker, args=(r, 2, port, build, tar, q)) for r in range(2)]
+    procs = [ctx.Process(target=_tree_worker, args=(r, 2, port, build, tar, q, snaphash_mode == "planned")) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=280) for _ in range(2)]
@@ -110,6 +112,8 @@ def test_two_ranks_tree_to_hashes_yaml(oracle, tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sum(r[2] for r in res) == len(sizes)
-    assert sum(r[3] for r in res) == sum(sizes) and all(r[4] == 0 for r in res)  # every byte through the kernels
+    assert sum(r[3] + r[4] for r in res) == sum(sizes)
+    if snaphash_mode == "gpu_only":
+        assert all(r[4] == 0 for r in res)  # every byte through the kernels
     for rank, y, *_ in res:
         assert y == want, rank

@@ -18,6 +18,7 @@ from test_f3_host import sample_inputs, _make_tree, f3  # noqa: F401  (the CPU m
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.kernels_only("the DEFLATE kernel alone: nothing in it is planned")
 def test_gpu_deflate_round_trips_and_equals_its_cpu_model(built_lib, f3):  # noqa: F811
     """Every sample: gzip.decompress(GPU output) == input, CRC/ISIZE right -- and the bytes equal the serial
     CPU model of the kernel (same chunking, hash chains, lazy parse, encoder), so the workgroup's pipeline is exact."""
@@ -43,6 +44,7 @@ def test_gpu_deflate_round_trips_and_equals_its_cpu_model(built_lib, f3):  # noq
             assert st["chunks"] == sum((p + 65535) // 65536 for p in pieces)
 
 
+@pytest.mark.kernels_only("the DEFLATE kernel alone: nothing in it is planned")
 def test_deflate_depth_is_the_models_depth(built_lib, f3):  # noqa: F811
     """snaphash_config.deflate_depth (ABI 4): the producer's effort -- hash-chain links walked per position.  At 8, 64 and
     128 the GPU's bytes equal the serial model's at that depth, gzip reads them back, and a deeper walk never writes more
@@ -341,6 +343,7 @@ def test_tarcreate_as_the_reference_tests_it(built_lib, tmp_path):
         clickdeb.tarCreate(str(tmp_path / "x.tar.zz"), builddir, None)  # "unknown compression extension"
 
 
+@pytest.mark.kernels_only("the DEFLATE kernel alone: nothing in it is planned")
 def test_gpu_deflate_equals_model_on_random_structures(built_lib, f3):  # noqa: F811
     """Forty synthetic inputs made of the things a parse can trip over -- copies from every distance up to beyond the
     window, of every length up to beyond 258, runs, literal bursts, cut at awkward sizes around the chunk and tile

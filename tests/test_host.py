@@ -21,19 +21,21 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert declared == set(_lib.EXPORTS)
     for s in declared:
         assert hasattr(built_lib, s), s
-    assert built_lib.snaphash_abi_version() == 4
+    assert built_lib.snaphash_abi_version() == 5
 
 
 def test_struct_layouts_match_header(built_lib):
     from snappy_amd import _lib
     assert ctypes.sizeof(_lib.Config) == 56
     assert _lib.Config.devices.offset == 32  # an ABI-1 caller passes struct_size 32: the prefix is unchanged
-    assert ctypes.sizeof(_lib.StatsEx) == 64
+    assert ctypes.sizeof(_lib.StatsEx) == 112 and _lib.StatsEx.planned_gpu_ms.offset == 64  # ABI 4 callers pass 64
     assert ctypes.sizeof(_lib.Stats) == 56
     assert ctypes.sizeof(_lib.Mismatch) == 8 + 4096
     assert ctypes.sizeof(_lib.Record) == 32
     assert ctypes.sizeof(_lib.EngineInfo) == 72 and _lib.EngineInfo.pinned_bytes.offset == 56  # ABI 3 callers pass 56
-    assert ctypes.sizeof(_lib.PlanModel) == 96 and _lib.PlanModel.gpu_seconds.offset == 56  # ABI 4
+    assert ctypes.sizeof(_lib.PlanModel) == 104 and _lib.PlanModel.gpu_seconds.offset == 56  # ABI 4 ...
+    assert _lib.PlanModel.fill_rate.offset == 96                                             # ... whose callers pass 96
+    assert ctypes.sizeof(_lib.PlanCalib) == 40
 
 
 def test_no_gpu_means_loud_failure(built_lib):

@@ -221,3 +221,91 @@ def test_cli_plan_verb_needs_no_device(built_lib, tmp_path):
     lines = r.stdout.decode().splitlines()
     assert lines[1].startswith("host") and lines[1].endswith("big.bin")   # 24 MiB alone on the GPU: 0.57 s; on a host core 18 ms
     assert lines[0].split()[0] in ("gpu", "host") and b"modelled" in r.stderr
+
+
+# ---- round 5: the model's constants are measured on the box, and a wrong one is corrected (planner.h PlanCalib) -------
+def _calib():
+    import ctypes
+    from snappy_amd import _lib
+    return _lib.PlanCalib(ctypes.sizeof(_lib.PlanCalib))
+
+
+def _observe(c, what, nbytes, seconds):
+    import ctypes
+    from snappy_amd import _lib
+    return _lib.lib().snaphash_calib_observe(ctypes.byref(c), what, float(nbytes), float(seconds))
+
+
+def _apply(c, from_files, **kw):
+    import ctypes
+    from snappy_amd import _lib
+    pm = _lib.PlanModel(ctypes.sizeof(_lib.PlanModel))
+    pm.from_files = from_files
+    for k, v in kw.items():
+        setattr(pm, k, v)
+    assert _lib.lib().snaphash_calib_apply(ctypes.byref(c), ctypes.byref(pm)) == 0
+    return pm.gpu_link, pm.fill_rate
+
+
+def test_a_wrong_link_constant_is_corrected_by_what_the_calls_measure(built_lib):
+    """VERDICT r4 item 4.  The model's 54/55 GB/s is one lease's PCIe link.  On a box whose copies run at 25 GB/s the
+    observations (HIP-event time of the H2D copies, one per staged call) move the calibrated link there -- the first one
+    at once, outliers only a quarter of the way -- and the plan of config 2 changes with it: a slower link leaves more of
+    the tree to the host threads."""
+    c = _calib()
+    assert _apply(c, 0) == (0.0, 0.0)                              # nothing measured: the model keeps its defaults
+    assert _observe(c, 0, 1 << 20, 1e-5) == 0 and c.n_dma == 0     # too small to mean anything
+    assert _observe(c, 0, 1 << 30, 1e-9) == 0 and c.n_dma == 0     # no box does that
+    assert _observe(c, 0, 256 * MiB, 256 * MiB / 25e9) == 1
+    link, _ = _apply(c, 0)
+    assert abs(link - 25e9 * 55.0 / 56.7) < 1e6                    # the first observation stands
+    assert _observe(c, 0, 256 * MiB, 256 * MiB / 50e9) == 1        # one odd call does not re-plan the box ...
+    assert abs(c.dma - (0.75 * 25e9 + 0.25 * 50e9)) < 1e6
+    for _ in range(12):                                            # ... a box that really is faster gets there
+        _observe(c, 0, 256 * MiB, 256 * MiB / 50e9)
+    assert 48e9 < c.dma <= 50e9
+    # an explicit link in the model is the caller's: calibration fills only what is unset
+    assert _apply(c, 0, gpu_link=40e9)[0] == 40e9
+
+    lens = [MiB] * 10001
+    slow = _calib()
+    _observe(slow, 0, 256 * MiB, 256 * MiB / 25e9)
+    link_slow, _ = _apply(slow, 1)
+    _, r_default = _plan(lens, from_files=1, host_lane_gain_pct=240)
+    _, r_slow = _plan(lens, from_files=1, host_lane_gain_pct=240, gpu_link=link_slow)
+    assert r_slow["host_bytes"] > r_default["host_bytes"] * 1.5, (r_default, r_slow)
+    # and the prediction follows: the same split costs the GPU part twice as long on the slow link
+    _, g_fast = _plan(lens, from_files=1, host_threads=1, cpus=2)
+    _, g_slow = _plan(lens, from_files=1, host_threads=1, cpus=2, gpu_link=link_slow)
+    assert g_slow["gpu_seconds"] > 1.8 * g_fast["gpu_seconds"]
+
+
+def test_fill_rate_calibration_and_what_it_changes(built_lib):
+    """One fill thread's rate: from memory it is measured at init, from files by the first staged call (wall x threads);
+    until a file has been read, a box whose cores copy memory at half the model's 9 GB/s is taken to pread at half the
+    model's 6.5 GB/s too."""
+    c = _calib()
+    assert _observe(c, 1, 64 * MiB, 64 * MiB / 4.5e9) == 1
+    assert abs(_apply(c, 0)[1] - 4.5e9) < 1e6
+    assert abs(_apply(c, 1)[1] - 3.25e9) < 1e6                     # scaled from the memory rate
+    assert _observe(c, 2, 512 * MiB, 512 * MiB / 5e9) == 1
+    assert abs(_apply(c, 1)[1] - 5e9) < 1e6                        # files measured: that is what counts
+    assert _observe(c, 2, 100, 1.0) == 0 and _observe(c, 7, 1e9, 1.0) < 0
+    # a fill thread at a fifth of the model's rate makes the fill, not the link, the bound of the GPU part
+    lens = [MiB] * 5000
+    _, fast = _plan(lens, from_files=1, host_threads=1, cpus=2, fill_threads=4)
+    _, slow = _plan(lens, from_files=1, host_threads=1, cpus=2, fill_threads=4, fill_rate=1.3e9)
+    assert slow["gpu_seconds"] > 2.0 * fast["gpu_seconds"]
+
+
+def test_abi4_sized_structs_are_still_taken(built_lib):
+    """A caller built against ABI 4 passes the shorter snaphash_plan_model (no fill_rate)."""
+    import ctypes
+    from snappy_amd import _lib
+    pm = _lib.PlanModel()
+    pm.struct_size = _lib.PlanModel.fill_rate.offset
+    pm.cpus = 16
+    arr = (ctypes.c_uint64 * 3)(MiB, MiB, 77)
+    assert _lib.lib().snaphash_plan_streams(arr, 3, ctypes.byref(pm), None) == 0
+    pm.struct_size = 8
+    assert _lib.lib().snaphash_plan_streams(arr, 3, ctypes.byref(pm), None) == _lib.EINVAL

@@ -271,6 +271,8 @@ def test_bench_starts_its_own_ranks_and_fails_loudly_without_gpus():
     # the parent itself never loaded torch: it is the ranks that say so
     src = open(os.path.join(ROOT, "bench.py")).read()
     body = src[src.index("def self_launch("):src.index("def main(")]
-    assert "import torch" not in body and "snappy_amd" not in body
+    import re
+    loads = re.compile(r"^\s*(import|from)\s+(torch|snappy_amd|oracle)\b", re.M)
+    assert not loads.search(body)
     head = src[src.index("def main("):src.index("sys.exit(self_launch(args))")]
-    assert "import torch" not in head and "snappy_amd" not in head
+    assert not loads.search(head)

@@ -656,3 +656,90 @@ def test_tree_with_a_directory_that_cannot_be_listed(built_lib, oracle, tmp_path
             assert c.verify(str(b), y, str(tar)) is None
     finally:
         os.chmod(str(b / "locked"), 0o755)
+
+
+@pytest.mark.kernels_only("names the configuration of every Context it makes")
+def test_the_plan_is_reported_beside_what_the_call_took_and_the_box_is_calibrated(built_lib, oracle, tmp_path):
+    """ABI 5: a ctx that may plan measures its box when it is made (the first engine's H2D rate, what
+    one thread copies into pinned staging), corrects both from every staged call, plans with them, and reports the
+    plan's modelled makespans beside the measured ones (snaphash_stats_ex).  snaphash_get_plan_model + snaphash_plan_streams
+    reproduce the ctx's own plan."""
+    import ctypes
+    from snappy_amd import Context, _lib
+    n = 1536
+    blob = np.random.default_rng(6).integers(0, 256, size=(n << 20) + 4096, dtype=np.uint8)
+    bufs = [blob[(i << 20) + i % 4096:((i + 1) << 20) + i % 4096] for i in range(n)]
+    with Context(flags=0) as c:
+        k0 = c.calib()
+        assert k0["n_dma"] == 1 and 5e9 < k0["dma"] < 200e9, k0                 # a PCIe link of some generation
+        assert k0["n_fill_mem"] == 1 and 0.5e9 < k0["fill_mem"] < 60e9, k0
+        m0 = c.plan_model(False)
+        assert abs(m0["gpu_link"] - k0["dma"] * 55.0 / 56.7) < 1e6 and abs(m0["fill_rate"] - k0["fill_mem"]) < 1e6
+        assert m0["host_lane_gain_pct"] in (100, 320) and m0["cpus"] == _lib.lib().snaphash_usable_cpus()
+        got = c.sha512_buffers(bufs)
+        ex = c.stats_ex()
+        st = c.stats()
+        assert ex["gpu_bytes"] > 0 and ex["host_bytes"] + ex["gpu_bytes"] == n << 20
+        assert ex["planned_gpu_ms"] > 0 and ex["gpu_ms"] > 0 and ex["hash_ms"] >= ex["gpu_ms"] and ex["plan_ms"] < 20
+        assert (ex["planned_host_ms"] > 0) == (ex["host_bytes"] > 0) and ex["planned_threads"] >= ex["host_threads_run"]
+        # the prediction is a prediction: within a factor of two on any box this suite has met (bench.py flags 25 %)
+        assert 0.5 < ex["gpu_ms"] / ex["planned_gpu_ms"] < 2.0, ex
+        k1 = c.calib()
+        assert k1["n_dma"] == 2 and k1["n_fill_mem"] >= 2                       # the call was an observation
+        assert 0.5 < k1["dma"] / k0["dma"] < 2.0                                # and agrees with the probe, roughly
+        # the ctx's model through the host-only planner gives the ctx's plan (same streams, same model => same split)
+        m1 = c.plan_model(False)
+        on_host, r = _lib.plan_streams([1 << 20] * n, **m1)
+        got2 = c.sha512_buffers(bufs)
+        ex2 = c.stats_ex()
+        assert sum(on_host) == ex2["host_streams"] and abs(r["gpu_seconds"] * 1e3 - ex2["planned_gpu_ms"]) < 1e-6
+        assert got2 == got
+        assert st["bytes_hashed"] == n << 20
+    for i in (0, 1, n // 2, n - 1):
+        assert got[i] == hashlib.sha512(bufs[i].tobytes()).digest()
+    with Context() as c:  # GPU only: no plan, no probe, zeros where a plan would be
+        c.sha512_buffers(bufs[:64])
+        ex = c.stats_ex()
+        assert ex["planned_gpu_ms"] == 0 and ex["planned_threads"] == 0 and ex["gpu_ms"] > 0 and c.calib()["n_fill_mem"] <= 1
+    # an ABI 4 caller's shorter snaphash_stats_ex is still filled
+    with Context(flags=0) as c:
+        c.sha512_buffers([b"x"])
+        s = _lib.StatsEx()
+        s.struct_size = _lib.StatsEx.planned_gpu_ms.offset
+        s.planned_gpu_ms = -1.0
+        assert _lib.lib().snaphash_get_stats_ex(c._h, ctypes.byref(s)) == 0
+        assert s.host_bytes == 1 and s.planned_gpu_ms == -1.0 and s.struct_size == _lib.StatsEx.planned_gpu_ms.offset
+
+
+@pytest.mark.kernels_only("runs in a child process that names its own configuration")
+def test_host_lanes_and_kept_descriptors_share_one_budget(built_lib, oracle, tmp_path):
+    """the host part opens a descriptor per lane (eight a thread) beside the descriptors the staging
+    fill keeps between batches; under a low RLIMIT_NOFILE (SNAPHASH_FLAG_KEEP_RLIMIT, soft 96) with 24 host threads the
+    two used to overrun the limit and the call failed with EMFILE where the reference's one-file-at-a-time loop
+    succeeds.  Now the call divides what the limit leaves, and an open that still finds no descriptor waits for one."""
+    import subprocess
+    import sys
+    sizes = [int(x) for x in _ragged_sizes(900, 41, 1 << 19)] + [300000] * 400 + [5 << 20, 2 << 20, 7]
+    build, tar = trees.make_synthetic_tree(str(tmp_path), sizes)
+    want = oracle.hashes_yaml(build, tar)
+    code = (
+        "import resource, sys\n"
+        "resource.setrlimit(resource.RLIMIT_NOFILE, (96, min(4096, resource.getrlimit(resource.RLIMIT_NOFILE)[1])))\n"
+        "sys.path.insert(0, %r)\n"
+        "from snappy_amd import Context, _lib\n"
+        "with Context(staging_bytes=8 << 20, host_threads=24, flags=_lib.FLAG_KEEP_RLIMIT) as c:\n"
+        "    assert resource.getrlimit(resource.RLIMIT_NOFILE)[0] == 96\n"
+        "    y = c.tree(%r, %r)\n"
+        "    ex = c.stats_ex()\n"
+        "    assert ex['host_bytes'] > 0 and ex['gpu_bytes'] > 0, ex\n"
+        "    assert ex['host_threads_run'] <= 24\n"
+        "    paths = [l.split(None, 1)[1] for l in open(%r).read().splitlines()]\n"
+        "    d = c.sha512_files(paths)\n"   # and the same list with no GPU part worth having: all lanes, all host
+        "sys.stdout.buffer.write(y)\n" % (ROOT, build, tar, str(tmp_path / "paths.txt")))
+    with open(str(tmp_path / "paths.txt"), "w") as f:
+        for dp, _, fs in os.walk(build):
+            for name in fs:
+                f.write("p %s\n" % os.path.join(dp, name))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-800:]
+    assert r.stdout == want

@@ -440,8 +440,11 @@ int snaphash_plan_streams(const uint64_t *lens, size_t n, snaphash_plan_model *m
 int snaphash_get_plan_model(const snaphash_ctx *ctx, int from_files, snaphash_plan_model *model);
 /* ABI 5, host-only: the calibration's update rule by itself (what a ctx applies after each staged call): an observation
  * of `bytes` moved in `seconds` -- what = 0: an engine's H2D copies (HIP event time), 1: one fill thread from memory,
- * 2: one fill thread preading files (wall x threads).  Returns 1 when the observation was taken, 0 when it was too
- * small or implausible to mean anything, negative on bad arguments.  snaphash_calib_apply writes the calibrated
+ * 2: one fill thread preading files (wall x threads); 3 / 4: a call that went to host threads whole measured no fill from
+ * memory / files, and the estimate moves a quarter of the way back to the model's default (bytes and seconds unused).
+ * Returns 1 when the observation was taken, 0 when it was too small or implausible to mean anything, negative on bad
+ * arguments.  How far an observation is believed: the link within a factor of four of the defaults' 56.7 GB/s, a fill
+ * thread down to half of its default and never above it (planner.h).  snaphash_calib_apply writes the calibrated
  * gpu_link / fill_rate into a model that has not set them (from_files decides which). */
 typedef struct snaphash_plan_calib {
     uint32_t struct_size; /* in: sizeof(snaphash_plan_calib) */

@@ -319,6 +319,30 @@ void FillPool::parallel_for(size_t n, unsigned threads, const std::function<void
     if (fn_threw_.exchange(false) || threw) throw std::bad_alloc();
 }
 
+// ---- run_on_threads: the process-wide helper pool ----------------------------------------------------------------
+
+void run_on_threads(unsigned T, const std::function<void(unsigned)>& fn)
+{
+    if (T <= 1) { fn(0); return; }
+    static std::mutex mu;
+    static FillPool* pool = [] { // (never destroyed: its threads sleep until the process ends; a static destructor would race with them at exit)
+        FillPool* p = new FillPool();
+        p->configure(64, {});
+        return p;
+    }();
+    if (T <= 65 && mu.try_lock()) {
+        std::lock_guard<std::mutex> lk(mu, std::adopt_lock);
+        // parallel_for hands out indices, not threads: an index is taken by whoever comes first, so give every index a
+        // thread's whole share of the work -- which is what fn(t) is
+        pool->parallel_for(T, T, [&fn](size_t t) { fn((unsigned)t); });
+        return;
+    }
+    ThreadJoiner th;
+    for (unsigned t = 1; t < T; ++t) th.spawn(fn, t);
+    fn(0);
+    th.join_all();
+}
+
 // ---- copy_to_staging ------------------------------------------------------------------------------------------
 
 #if defined(__x86_64__)

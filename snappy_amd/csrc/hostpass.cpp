@@ -139,11 +139,14 @@ void hex_lower(const uint8_t d[64], char out[128])
     for (int i = 0; i < 64; ++i) { out[2 * i] = x[d[i] >> 4]; out[2 * i + 1] = x[d[i] & 15]; }
 }
 
-// the records [lo, hi) of recs; file_digests already points at the digest of the first regular record among them
-static int emit_records(const std::vector<Record>& recs, size_t lo, size_t hi, const uint8_t* file_digests, std::string& out)
+// the records [lo, hi) of recs; file_digests already points at the digest of the first regular record among them.
+// hex_at (skeleton): no digests yet -- 128 zeros stand in, and where each run starts (relative to out) is noted.
+static int emit_records(const std::vector<Record>& recs, size_t lo, size_t hi, const uint8_t* file_digests, std::string& out,
+                        std::vector<size_t>* hex_at = nullptr)
 {
     char hex[128], num[32];
     size_t fi = 0;
+    if (hex_at) memset(hex, '0', sizeof hex);
     for (size_t k = lo; k < hi; ++k) {
         const Record& r = recs[k];
         char mode[11];
@@ -156,22 +159,26 @@ static int emit_records(const std::vector<Record>& recs, size_t lo, size_t hi, c
         if (r.is_regular) { // size (*int64, omitempty on nil only: "size: 0" IS emitted), then sha512
             snprintf(num, sizeof num, "%lld", (long long)r.size);
             out += "  size: "; out += num; out += '\n';
-            hex_lower(file_digests + 64 * fi++, hex);
-            out += "  sha512: "; out.append(hex, 128); out += '\n';
+            if (!hex_at) hex_lower(file_digests + 64 * fi++, hex);
+            out += "  sha512: ";
+            if (hex_at) hex_at->push_back(out.size());
+            out.append(hex, 128); out += '\n';
         }
         out += "  mode: "; out.append(mode, 10); out += '\n';
     }
     return SNAPHASH_OK;
 }
 
-int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64], const uint8_t* file_digests,
-              std::string& out)
+static int emit_yaml_impl(const std::vector<Record>& recs, const uint8_t* archive_digest, const uint8_t* file_digests,
+                          std::string& out, std::vector<size_t>* hex_at, unsigned max_threads = 8)
 {
     char hex[128];
     out.clear();
     out.reserve(64 + recs.size() * 220);
-    hex_lower(archive_digest, hex);
+    if (hex_at) { hex_at->clear(); memset(hex, '0', sizeof hex); }
+    else hex_lower(archive_digest, hex);
     out += "archive-sha512: "; // hashes.go:106
+    if (hex_at) hex_at->push_back(out.size());
     out.append(hex, 128);
     out += '\n';
     if (recs.empty()) { // yaml.v2 renders an empty slice in flow style (unpinned by the reference)
@@ -181,8 +188,8 @@ int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64],
     out += "files:\n"; // untagged field Files -> lower-cased key (hashes.go:109)
     // Records are independent: a large tree is written in ranges on a few threads and the pieces are joined in order
     // (10 100 records: 2.1 ms on one thread -- on rank 0 of an 8-GPU pass that is serial time behind the gather).
-    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(8u, usable_cpus()), recs.size() / 1024));
-    if (T <= 1) return emit_records(recs, 0, recs.size(), file_digests, out);
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(std::max(1u, max_threads), usable_cpus()), recs.size() / 1024));
+    if (T <= 1) return emit_records(recs, 0, recs.size(), file_digests, out, hex_at);
     std::vector<size_t> first_digest(T + 1, 0); // regular records in front of each range
     {
         size_t fi = 0;
@@ -192,23 +199,44 @@ int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64],
         }
     }
     std::vector<std::string> piece(T);
+    std::vector<std::vector<size_t>> piece_at(hex_at ? T : 0);
     std::vector<int> prc(T, 0);
     auto work = [&](unsigned t) {
         const size_t lo = recs.size() * t / T, hi = recs.size() * (t + 1) / T;
         piece[t].reserve((hi - lo) * 220);
-        prc[t] = emit_records(recs, lo, hi, file_digests ? file_digests + 64 * first_digest[t] : nullptr, piece[t]);
+        prc[t] = emit_records(recs, lo, hi, file_digests ? file_digests + 64 * first_digest[t] : nullptr, piece[t], hex_at ? &piece_at[t] : nullptr);
     };
-    {
-        ThreadJoiner th;
-        for (unsigned t = 1; t < T; ++t) th.spawn(work, t);
-        work(0);
-        th.join_all();
-    }
+    run_on_threads(T, work);
     for (unsigned t = 0; t < T; ++t) { // the first error in record order, as the serial loop would have met it
         if (prc[t]) return prc[t];
+        if (hex_at)
+            for (size_t at : piece_at[t]) hex_at->push_back(out.size() + at);
         out += piece[t];
     }
     return SNAPHASH_OK;
+}
+
+int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64], const uint8_t* file_digests,
+              std::string& out)
+{
+    return emit_yaml_impl(recs, archive_digest, file_digests, out, nullptr);
+}
+
+int emit_yaml_skeleton(const std::vector<Record>& recs, YamlSkeleton& sk, unsigned max_threads)
+{
+    return emit_yaml_impl(recs, nullptr, nullptr, sk.text, &sk.hex_at, max_threads);
+}
+
+void yaml_fill_digests(YamlSkeleton& sk, const uint8_t archive_digest[64], const uint8_t* file_digests)
+{
+    if (sk.hex_at.empty()) return;
+    hex_lower(archive_digest, &sk.text[sk.hex_at[0]]);
+    const size_t n = sk.hex_at.size() - 1;
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(8u, usable_cpus()), n / 2048));
+    auto work = [&](unsigned t) {
+        for (size_t i = n * t / T; i < n * (t + 1) / T; ++i) hex_lower(file_digests + 64 * i, &sk.text[sk.hex_at[i + 1]]);
+    };
+    run_on_threads(T, work);
 }
 
 // ---- tolerant parser for yaml.v2's rendering of hashesYaml ------------------------
@@ -453,17 +481,13 @@ int parse_yaml(const char* text, size_t len, ParsedHashes& out)
             std::vector<ParsedHashes> part(T);
             std::vector<int> prc(T, SNAPHASH_OK);
             std::vector<char> top(T, 0);
-            {
-                ThreadJoiner th;
-                auto work = [&](unsigned t) {
-                    bool tl = false;
-                    prc[t] = cut[t] < cut[t + 1] ? parse_lines(lines, cut[t], cut[t + 1], true, part[t], &tl) : SNAPHASH_OK;
-                    top[t] = tl;
-                };
-                for (unsigned t = 1; t < T; ++t) th.spawn(work, t);
-                work(0);
-                th.join_all(); // raises what a worker threw (an allocation that failed): a lost worker must not read as a clean, short file list
-            }
+            // (run_on_threads raises what a worker threw -- an allocation that failed: a lost worker must not read as a clean,
+            // short file list)
+            run_on_threads(T, [&](unsigned t) {
+                bool tl = false;
+                prc[t] = cut[t] < cut[t + 1] ? parse_lines(lines, cut[t], cut[t + 1], true, part[t], &tl) : SNAPHASH_OK;
+                top[t] = tl;
+            });
             bool clean = true;
             for (unsigned t = 0; t < T; ++t) clean = clean && prc[t] == SNAPHASH_OK && !top[t];
             if (clean) {

@@ -43,6 +43,16 @@ bool name_emittable(const std::string& s);
 void hex_lower(const uint8_t d[64], char out[128]);
 int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64], const uint8_t* file_digests,
               std::string& out);
+// The same document written BEFORE the digests exist (round 5: the YAML of a tree no longer waits behind the last kernel):
+// every sha512 value is 128 zeros and hex_at says where each one starts -- [0] the archive's, then one per regular record
+// in record order.  yaml_fill_digests writes the digests in (ranges on a few threads for a large tree); the result is
+// byte for byte what emit_yaml writes.
+struct YamlSkeleton {
+    std::string text;
+    std::vector<size_t> hex_at;
+};
+int emit_yaml_skeleton(const std::vector<Record>& recs, YamlSkeleton& out, unsigned max_threads = 8 /* 1: on the calling thread alone (a background build beside a pass that needs the cores) */);
+void yaml_fill_digests(YamlSkeleton& sk, const uint8_t archive_digest[64], const uint8_t* file_digests);
 int parse_yaml(const char* text, size_t len, ParsedHashes& out);
 bool digest_matches_hex(const uint8_t d[64], const std::string& hex);
 int lpt_assign(const uint64_t* lens, size_t n, int nshards, int32_t* shard_of);

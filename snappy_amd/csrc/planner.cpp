@@ -36,30 +36,47 @@ bool take(double& est, unsigned& count, double rate, double lo, double hi)
 constexpr double kLinkOfDmaFiles = 54.0 / 56.7, kLinkOfDmaMem = 55.0 / 56.7;
 } // namespace
 
+// An observation enters the estimate already cut to what apply() would believe of it (below), so that one absurd call --
+// the first read of freshly written tmpfs files measured 0.21 GB/s a thread -- costs the estimate one step, not eight.
 bool PlanCalib::observe_dma(double bytes, double seconds)
 {
     if (bytes < (double)(4u << 20) || seconds < 50e-6) return false;
-    return take(dma, n_dma, bytes / seconds, 2e9, 400e9);
+    const double rate = bytes / seconds;
+    if (!(rate >= 2e9 && rate <= 400e9)) return false;
+    return take(dma, n_dma, std::min(4.0 * 56.7e9, std::max(0.25 * 56.7e9, rate)), 2e9, 400e9);
 }
 
 bool PlanCalib::observe_fill(bool files, double bytes, double thread_seconds)
 {
     if (bytes < (double)(4u << 20) || thread_seconds < 50e-6) return false;
-    return files ? take(fill_files, n_fill_files, bytes / thread_seconds, 0.2e9, 100e9)
-                 : take(fill_mem, n_fill_mem, bytes / thread_seconds, 0.2e9, 100e9);
+    const double rate = bytes / thread_seconds, dflt = files ? 6.5e9 : 9e9;
+    if (!(rate >= 0.05e9 && rate <= 200e9)) return false;
+    const double cut = std::min(2.0 * dflt, std::max(0.5 * dflt, rate));
+    return files ? take(fill_files, n_fill_files, cut, 0.05e9, 200e9) : take(fill_mem, n_fill_mem, cut, 0.05e9, 200e9);
 }
 
+void PlanCalib::relax(bool files)
+{
+    double& est = files ? fill_files : fill_mem;
+    const double dflt = files ? 6.5e9 : 9e9;
+    if (est > 0 && est < dflt) est = 0.75 * std::max(est, 0.5 * dflt) + 0.25 * dflt;
+}
+
+// What the observations may do to the model.  The link: anything a PCIe generation or two away from the 56.7 GB/s the
+// defaults were taken on.  A fill thread: DOWN to half of the default, never up -- the default (9 / 6.5 GB/s) is not what
+// a thread can move (a thread alone copies 40 GB/s out of DRAM on the box the defaults come from, and 12-14 inside the
+// pipeline: profiles/r05_calibration.txt) but what makes the model's "cores" bound come out right beside host threads
+// that compete with it; a box whose fills are slower scales it down, a faster one leaves it alone.  And an observation is
+// not believed beyond that range whatever it says: the first read of freshly written tmpfs files measured 0.22 GB/s a
+// thread, once, and a model that believed it would have sent every later call to the host threads for good.
 void PlanCalib::apply(PlanModel& m) const
 {
-    if (m.gpu_link <= 0 && dma > 0) m.gpu_link = dma * (m.from_files ? kLinkOfDmaFiles : kLinkOfDmaMem);
+    if (m.gpu_link <= 0 && dma > 0)
+        m.gpu_link = std::min(4.0 * 56.7e9, std::max(0.25 * 56.7e9, dma)) * (m.from_files ? kLinkOfDmaFiles : kLinkOfDmaMem);
     if (m.fill_rate <= 0) {
-        if (m.from_files) {
-            // no file has been read yet: a box whose cores copy memory slower or faster than the model's preads by that much too
-            if (fill_files > 0) m.fill_rate = fill_files;
-            else if (fill_mem > 0) m.fill_rate = 6.5e9 * std::min(4.0, std::max(0.25, fill_mem / 9e9));
-        } else if (fill_mem > 0) {
-            m.fill_rate = fill_mem;
-        }
+        const double dflt = m.from_files ? 6.5e9 : 9e9;
+        const double seen = m.from_files ? fill_files : fill_mem;
+        if (seen > 0) m.fill_rate = std::min(dflt, std::max(0.5 * dflt, seen));
     }
 }
 

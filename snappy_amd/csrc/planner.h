@@ -35,9 +35,10 @@ struct PlanModel {
 
 // What THIS box does, as far as the library has seen it (round 5: the model's constants were one lease's 16-CPU quota and
 // one PCIe link; the 8-GPU node is another box).  The two constants that move most between boxes -- what an engine's
-// copy engine moves over its link and what one fill thread moves into the staging buffers -- are measured when a ctx
-// that may plan is created (a few timed copies, ~1 ms) and corrected by every staged call afterwards (HIP events of
-// the H2D copies; wall x threads of the fills); snaphash_stats_ex sets the model's prediction beside what the call took.
+// copy engine moves over its link and what one fill thread moves into the staging buffers -- are measured: the link
+// when a ctx that may plan is created (two timed copies, ~1 ms) and by every staged call afterwards (HIP events of
+// the H2D copies), the fill threads by every staged call but a ctx's first (wall x threads of its fills);
+// snaphash_stats_ex sets the model's prediction beside what the call took.  apply() says how far an observation is believed.
 // Host-only arithmetic: the CPU suite drives it through snaphash_calib_observe.
 struct PlanCalib {
     double dma = 0;         // B/s one engine's H2D copies run at (HIP events); 0 = not measured: the model's default link
@@ -48,6 +49,10 @@ struct PlanCalib {
     // Too small to mean anything (under 4 MiB, under 50 us) or outside what any box does: ignored (returns false).
     bool observe_dma(double bytes, double seconds);
     bool observe_fill(bool files, double bytes, double thread_seconds);
+    // A call that was planned onto host threads whole measured no fill: a low estimate that caused that plan would never be
+    // corrected.  Such a call moves the estimate a quarter of the way back to the model's default, so that the GPU part is
+    // tried again -- and measured again -- after a few of them.
+    void relax(bool files);
     void apply(PlanModel& m) const; // fills gpu_link / fill_rate of a model that has not set them
 };
 

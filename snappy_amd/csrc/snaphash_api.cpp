@@ -153,6 +153,8 @@ struct DevCtx {
     unsigned fill_cap = 12;    // most fill threads this engine uses (the ctx divides the usable CPUs among its engines)
     unsigned fill_call_cap = 0; // fewer than that for the call in progress (a rank's share of the node's cores; 0 = no)
     snaphash_ctx* owner = nullptr; // for what the engine measures about the box (planner.h PlanCalib)
+    unsigned owner_cpus_per_engine = 0; // usable CPUs over the ctx's engines
+    uint64_t staged_calls = 0;  // hash_sources calls completed on this engine
     double fill_thread_s = 0;   // this call: wall x threads of its staging fills ...
     uint64_t fill_bytes = 0;    // ... and the bytes they moved
     FillPool pool;
@@ -499,7 +501,7 @@ int do_read_op(const Source& s, const ReadOp& op, FdCache* cache = nullptr)
 
 // Fills a staging slot: the engine's pool of fill threads (on the GPU's NUMA node, hostfill.h) runs the operations.
 void run_reads(DevCtx* c, const std::vector<Source>& src, const std::vector<ReadOp>& ops, std::atomic<int>& first_err,
-               std::atomic<int64_t>& first_err_src, FdCache* cache = nullptr)
+               std::atomic<int64_t>& first_err_src, FdCache* cache = nullptr, bool alone = false)
 {
     // Staging-fill threads, measured on the GPU box (tools/copy_threads_sweep.sh): copies from caller memory
     // peak at 6 threads (44 GiB/s end to end; 16 threads: 33 -- they fight the concurrent H2D DMA for host
@@ -513,6 +515,9 @@ void run_reads(DevCtx* c, const std::vector<Source>& src, const std::vector<Read
     const bool from_memory = !ops.empty() && src[ops[0].src].mem != nullptr;
     unsigned cap = forced ? (unsigned)forced : std::min(c->fill_cap, from_memory ? 6u : 12u);
     if (!forced && c->fill_call_cap) cap = std::min(cap, c->fill_call_cap);
+    // the first fill of a call has the machine to itself (no copy in flight to fight for memory bandwidth, no kernel to feed):
+    // every core the engine may use takes part
+    if (!forced && alone && !c->fill_call_cap && c->owner) cap = std::max(cap, std::min(c->fill_cap * 2u, c->owner_cpus_per_engine));
     const unsigned T = (unsigned)std::min<size_t>(cap, std::max<size_t>(1, ops.size() / 4));
     const double t_fill0 = now_ms();
     struct FillAccount { // what the fill threads of this box move (planner.h PlanCalib): wall x threads, bytes
@@ -593,8 +598,30 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         if (!ss.copied) HIP_TRY(c, hipEventCreateWithFlags(&ss.copied, hipEventDisableTiming));
         ss.busy = false;
     }
+    const size_t n_active0 = active.size();
+    // lab knobs, read once a CALL (so that one process can alternate settings between passes: tools/ramp_ab.py)
+    const size_t new_cap = [] { // streams a batch may BEGIN (file sources, trees of more than 2 048 streams); SNAPHASH_NEW_PER_BATCH=0: no cap
+        const char* e = getenv("SNAPHASH_NEW_PER_BATCH");
+        return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)1024;
+    }();
+    const bool hold_back_on = [] { const char* e = getenv("SNAPHASH_HOLD_BACK"); return !e || atoi(e) != 0; }();
+    bool held_back = false; // the last batch of a link-bound job has been cut in two (below)
+    const unsigned ramp_shift = [] { // the first batch of a large job is S_full >> this
+        const char* e = getenv("SNAPHASH_RAMP_SHIFT");
+        const unsigned long v = e ? strtoul(e, nullptr, 10) : 3ul;
+        return (unsigned)std::min<unsigned long>(std::max<unsigned long>(v, 1), 8);
+    }();
+    // ... of a job of many streams (link-bound), "first fraction in 1/64ths, growth per batch in percent": 24,115 = three
+    // eighths of a batch first, 15 % more each time (below)
+    unsigned ramp_first64 = 24, ramp_growth_pct = 115;
+    if (const char* e = getenv("SNAPHASH_RAMP_MANY")) {
+        unsigned a = 0, b = 0;
+        if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 64 && b >= 100 && b <= 400) { ramp_first64 = a; ramp_growth_pct = b; }
+    }
     unsigned batch = 0;
     double t_wait = 0, t_plan = 0, t_read = 0, t_launch = 0; // where the host side of the engine spends its time (SNAPHASH_TRACE_TREE)
+    const double t_engine0 = now_ms();
+    double t_first_copy = 0; // host clock: the first H2D is enqueued this long after the engine started
 
     while (!active.empty()) {
         const unsigned q = batch % nsub;
@@ -614,10 +641,22 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         // a slot and the last ones halve what is left -- invisible on a 10 GiB job, a fifth of the time of the 1.3 GiB
         // shard one of eight ranks gets.  A job that fits one slot is one batch.
         long double total_rem = 0;
-        for (uint32_t id : active) total_rem += (long double)(src[id].gpu_len - done[id]);
+        size_t n_started = 0;
+        for (uint32_t id : active) { total_rem += (long double)(src[id].gpu_len - done[id]); n_started += done[id] != 0; }
         uint64_t S = S_full;
         if (job_bytes + kAlign * n > S_full) {
-            if (batch < 3) {
+            if (n_active0 > 2048 && ramp_growth_pct > 100) {
+                // Many streams: the link is the bound, and the fill threads are only ~1.3 x as fast as the link (75 against
+                // 57 GB/s).  The link idles while the first batch is filled, and again before every batch that takes longer
+                // to fill than its predecessor takes to copy -- doubling batches (rounds 1-4: 1/8, 1/4, 1/2, 1) lose
+                // S x (2 / 75 - 1 / 57 GB/s) at every step: 3.5 ms in all on config 2, measured 3.6
+                // (profiles/r05_tree_events.txt).  A batch that grows by less than fill rate / link rate a step never
+                // makes the link wait: three eighths of a batch first, 15 % more each time (tools/ramp_ab.py; profiles/r05_ramp.txt:
+                // the link idle 1.4 + 1.1 ms at the start instead of 1.0 + 4.8).
+                double f = (double)ramp_first64 / 64.0;
+                for (unsigned k = 0; k < batch && f < 1.0; ++k) f *= (double)ramp_growth_pct / 100.0;
+                if (f < 1.0) S = std::max<uint64_t>((uint64_t)((double)S_full * f) & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20));
+            } else if (batch < ramp_shift) {
                 // ... but never so small that only some streams get their floor: a batch costs the kernel chain its LARGEST
                 // share's time, so 256 streams at 32 KiB cost what all 1 250 at 32 KiB would (the file-source shard's first
                 // three batches: 0.75 ms of kernel each for 8, 16 and 32 MiB; profiles/r04_shard_trace.txt)
@@ -627,7 +666,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
                 // (Finer steps -- x 1.4 a batch from 16 MiB, eight of them -- were tried for that regime and left the link idle
                 // MORE, 4.5 ms against 3.5: every batch costs ~0.4 ms of planning and hand-over whatever its size.)
                 const uint64_t every = active.size() <= 2048 ? std::min<uint64_t>(S_full, (seg_floor + kAlign) * (uint64_t)active.size()) : 0;
-                S = std::max<uint64_t>({(S_full >> (3 - batch)) & ~(uint64_t)(kAlign - 1), every & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20)});
+                S = std::max<uint64_t>({(S_full >> (ramp_shift - batch)) & ~(uint64_t)(kAlign - 1), every & ~(uint64_t)(kAlign - 1), std::min<uint64_t>(S_full, 1u << 20)});
             }
             if (total_rem < 2 * (long double)S) { // the end: half of what is left, while every stream can still get its floor
                 const uint64_t half = ((uint64_t)(total_rem / 2) + kAlign * active.size()) & ~(uint64_t)(kAlign - 1);
@@ -635,7 +674,15 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
                 if (half >= least) S = std::min(S, half);
             }
         }
-        const uint64_t floor_q = std::max<uint64_t>(seg_floor, (S / kTargetStreams) & ~(uint64_t)(kAlign - 1));
+        // A file's FIRST segment costs an open(), and every open of a process takes the lock of its one descriptor table
+        // (~3 us alone, ~19 us each with twelve threads at it).  A tree of many files used to begin all of
+        // them within its first four batches -- config 2: 10 001 opens in the first 480 MiB, whose fills ran at 40-50 GB/s
+        // where later ones run at 76, and the link idled 6 ms of the ramp (profiles/r05_tree_events_before.txt).  So a
+        // batch begins at most new_cap streams; the rest of it goes to streams already open (kept descriptors: a pread
+        // each).  Streams nobody has begun go in front of those served at the floor, so every batch begins its share.
+        const bool cap_new = new_cap != 0 && !from_memory && n_active0 > 2048;
+        const size_t n_serve = cap_new ? std::min<size_t>(kTargetStreams, n_started + std::min<size_t>(new_cap, active.size() - n_started)) : kTargetStreams;
+        const uint64_t floor_q = std::max<uint64_t>(seg_floor, (S / std::max<size_t>(1, n_serve)) & ~(uint64_t)(kAlign - 1));
         // What the shares are taken of: the batch less the alignment every segment may cost.  Without that the shares of
         // ALL streams came to a whole batch, the padding pushed the last dozen streams of the list out of every batch, and
         // they were hashed at the end, alone, at 44 MB/s each (5 000 x 1 MiB: the last four kernels took 26 ms instead of
@@ -656,14 +703,29 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         // length exceeds the floor (the long ones that set the makespan) stay in front of both and are served every time.
         std::vector<uint32_t> still, skipped, floor_still;
         still.reserve(active.size());
+        // The last batch of a link-bound job: nothing overlaps its kernel, which takes what its LARGEST share takes at a
+        // stream's 44 MB/s -- 64 KiB shares: 1.5-1.7 ms behind the last copy (profiles/r05_tree_events.txt).  So the batch
+        // that would be the last leaves 16 KiB of every stream behind for one more, whose kernel is 0.4 ms.
+        constexpr uint64_t kHold = 16u << 10;
+        const bool hold_back = hold_back_on && !held_back && n_active0 > 2048 && total_rem <= (long double)S_share && total_rem > (long double)(8u << 20);
+        if (hold_back) held_back = true;
         bool full = false;
+        size_t n_new = 0;
         for (uint32_t id : active) {
             if (full) { skipped.push_back(id); continue; }
+            if (cap_new && done[id] == 0 && src[id].gpu_len != 0) {
+                if (n_new >= new_cap) { skipped.push_back(id); continue; } // begun by a later batch
+                ++n_new;
+            }
             const uint64_t rem = src[id].gpu_len - done[id];
             uint64_t quota = total_rem > (long double)S ? (uint64_t)((long double)rem * (long double)S_share / total_rem) : rem;
             const bool at_floor = (quota & ~(uint64_t)(kAlign - 1)) < floor_q;
             quota = std::max(quota & ~(uint64_t)(kAlign - 1), floor_q); // a multiple of 128: segments are whole blocks
-            const uint64_t take = rem <= quota ? rem : quota;
+            uint64_t take = rem <= quota ? rem : quota;
+            if (hold_back) {
+                if (rem <= kHold + kHold / 2) { skipped.push_back(id); continue; } // all of it in the batch behind this one
+                take = std::min<uint64_t>(take, (rem - kHold) & ~(uint64_t)(kAlign - 1));
+            }
             const uint64_t at = (used + kAlign - 1) & ~(uint64_t)(kAlign - 1);
             if (at + take > S) { full = true; skipped.push_back(id); continue; }
             const bool last = take == rem;
@@ -694,12 +756,16 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         const double tb2 = now_ms();
         t_plan += tb2 - tb1;
 
-        run_reads(c, src, ops, first_err, first_err_src, from_memory ? nullptr : &fds);
+        run_reads(c, src, ops, first_err, first_err_src, from_memory ? nullptr : &fds, batch == 0);
         if (first_err.load()) break;
         const double tb3 = now_ms();
         t_read += tb3 - tb2;
+        if (trace_batches)
+            fprintf(stderr, "snaphash engine %d: batch %u: at %.2f ms: waited %.2f, planned %.2f, filled %.2f ms (%zu streams begun, %.1f GB/s)\n", c->index, batch,
+                    tb0 - t_engine0, tb1 - tb0, tb2 - tb1, tb3 - tb2, n_new, (double)used / ((tb3 - tb2) * 1e6 + 1e-9));
 
         if (used) { // copy stream: the slot's previous kernel was already waited for above
+            if (batch == 0) t_first_copy = now_ms() - t_engine0;
             EventPair* ev = next_events(c, 1);
             if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
             HIP_TRY(c, hipEventRecord(ev->a, c->copy_stream));
@@ -715,11 +781,30 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     }
 
     const double ts0 = now_ms();
-    rc = sync_ctx(c);
     static const bool trace_tree = getenv("SNAPHASH_TRACE_TREE") != nullptr;
+    float gpu_span = 0, copy_busy = 0, copy_span = 0; // first copy's start -> last kernel's end; the copies' own time; first copy's start -> last copy's end
+    if (trace_tree && c->ev_used > 1) {
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamSynchronize(c->stream);
+        size_t first_copy = c->ev_used, last_copy = 0, last_kernel = 0;
+        for (size_t i = 0; i < c->ev_used; ++i) {
+            float ms = 0;
+            if (c->ev_pool[i].kind == 1) {
+                if (first_copy == c->ev_used) first_copy = i;
+                last_copy = i;
+                if (hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b) == hipSuccess) copy_busy += ms;
+            } else if (c->ev_pool[i].kind == 0) last_kernel = i;
+        }
+        if (first_copy < c->ev_used) {
+            (void)hipEventElapsedTime(&gpu_span, c->ev_pool[first_copy].a, c->ev_pool[last_kernel].b);
+            (void)hipEventElapsedTime(&copy_span, c->ev_pool[first_copy].a, c->ev_pool[last_copy].b);
+        }
+    }
+    rc = sync_ctx(c);
     if (trace_tree)
-        fprintf(stderr, "snaphash engine %d: %u batches; waiting for a slot %.1f ms, planning %.1f ms, reads %.1f ms, enqueue %.1f ms, drain %.1f ms\n",
-                c->index, batch, t_wait, t_plan, t_read, t_launch, now_ms() - ts0);
+        fprintf(stderr, "snaphash engine %d: %u batches; waiting for a slot %.1f ms, planning %.1f ms, reads %.1f ms, enqueue %.1f ms, drain %.1f ms; "
+                        "first copy enqueued at %.2f ms, copies busy %.2f of %.2f ms, first copy -> last kernel %.2f ms, engine %.2f ms\n",
+                c->index, batch, t_wait, t_plan, t_read, t_launch, now_ms() - ts0, t_first_copy, copy_busy, copy_span, gpu_span, now_ms() - t_engine0);
     for (SubSlot& ss : c->sub) ss.busy = false;
     if (rc) return rc;
     if (first_err.load()) {
@@ -736,7 +821,12 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     if (c->owner) { // what this call says about the box: the copies' own rate (HIP events) and what a fill thread moved
         std::lock_guard<std::mutex> lk(c->owner->calib_mu);
         c->owner->calib.observe_dma((double)job_bytes, c->stats.h2d_ms * 1e-3);
-        c->owner->calib.observe_fill(!from_memory, (double)c->fill_bytes, c->fill_thread_s);
+        // (not the engine's first staged call: its fill threads are being created, its staging pages touched for the first time)
+        // ... nor a call that took three times what its plan said: whatever happened there (cold page cache, a neighbour on
+        // the box) is not what the next call will meet
+        const double planned = c->owner->ex.planned_gpu_ms, took = now_ms() - t_engine0;
+        if (c->staged_calls++ > 0 && !(planned > 0 && took > 3.0 * planned))
+            c->owner->calib.observe_fill(!from_memory, (double)c->fill_bytes, c->fill_thread_s);
     }
     return SNAPHASH_OK;
 }
@@ -881,6 +971,18 @@ double measure_host_rate()
         if (dt > 0) best = std::max(best, (double)buf.size() / dt);
     }
     return best > 50e6 ? best : 0.40e9;
+}
+
+// descriptors this process holds right now (the entries of /proc/self/fd, less the one the listing itself uses); 0 = unknown
+int64_t open_descriptors()
+{
+    DIR* d = opendir("/proc/self/fd");
+    if (!d) return 0;
+    int64_t n = 0;
+    while (struct dirent* e = readdir(d))
+        if (e->d_name[0] != '.') ++n;
+    closedir(d);
+    return n > 0 ? n - 1 : 0;
 }
 
 PlanModel plan_model_of(const snaphash_ctx* x, bool from_files)
@@ -1030,15 +1132,20 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
         struct rlimit rl;
         int64_t soft = 1024;
         if (getrlimit(RLIMIT_NOFILE, &rl) == 0) soft = rl.rlim_cur == RLIM_INFINITY ? 65536 : (int64_t)rl.rlim_cur;
-        const int64_t total = std::max<int64_t>(2, soft - std::min<int64_t>(512, soft / 2));
+        // what is not ours: the descriptors the process holds right now (+ a few for what it opens meanwhile), and at
+        // least the reserve snaphash_init leaves an application (512, or half of a small limit)
+        const int64_t reserve = std::max<int64_t>(open_descriptors() + 16, std::min<int64_t>(512, soft / 2));
+        // a fill thread holds one descriptor for the length of a pread when its file's is not a kept one
+        const int64_t transient = gpu_part ? (int64_t)std::min(x->d0()->fill_cap, 12u) * (int64_t)nd : 0;
+        const int64_t pool = std::max<int64_t>(2, soft - reserve - transient);
         int64_t lanes_fds = (int64_t)nh * host_lanes;
-        const int64_t lanes_cap = gpu_part ? std::max<int64_t>(1, total / 2) : total;
+        const int64_t lanes_cap = gpu_part ? std::max<int64_t>(1, pool / 2) : pool;
         if (lanes_fds > lanes_cap) {
             if ((int64_t)nh > lanes_cap) nh = (unsigned)lanes_cap;
             host_lanes = (unsigned)std::max<int64_t>(1, lanes_cap / nh);
             lanes_fds = (int64_t)nh * host_lanes;
         }
-        for (auto& d : x->dev) d->fd_call_budget = std::max<int64_t>(0, (total - lanes_fds) / (int64_t)nd);
+        for (auto& d : x->dev) d->fd_call_budget = std::max<int64_t>(0, (pool - lanes_fds) / (int64_t)nd);
     }
     auto run_host = [&](unsigned t) {
         const double t0 = now_ms();
@@ -1081,6 +1188,10 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
         th.join_all();
         dth.join_all();
         return fail(x, SNAPHASH_ENOMEM, "could not start a worker thread");
+    }
+    if (!gpu_part && !x->gpu_only) { // (no fill will be measured by this call: planner.h PlanCalib::relax)
+        std::lock_guard<std::mutex> lk(x->calib_mu);
+        x->calib.relax(src[0].path != nullptr);
     }
     if (!gpu_part) { if (nh) run_host(0); }
     else if (nd == 1) run_dev(0);
@@ -1265,11 +1376,12 @@ static void destroy_dev(DevCtx* c)
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
-// The two constants of the planner's model that differ most from box to box, measured where the ctx is made (~1-2 ms):
-// what the first engine's copy engine moves over its link -- two timed H2D copies out of pinned memory, a quarter and a
-// whole of 8 MiB, so that what a copy costs whatever its size drops out of the difference -- and what one thread copies
-// from ordinary memory into pinned staging.  Every staged call corrects both afterwards (hash_sources).  Never fatal: a
-// probe that cannot run leaves the model's defaults in place.
+// The constant of the planner's model that differs most from box to box, measured where the ctx is made (~1 ms): what the
+// first engine's copy engine moves over its link -- two timed H2D copies out of pinned memory, a quarter and a whole of
+// 8 MiB, so that what a copy costs whatever its size drops out of the difference.  Every staged call corrects it
+// afterwards, and measures what a fill thread moves (hash_sources; a probe of ONE thread copying 4 MiB was tried here and
+// says 46 GB/s where a thread inside the pipeline moves 12-14: profiles/r05_calibration.txt).  Never fatal: a probe that
+// cannot run leaves the model's defaults in place.
 static void calibrate_at_init(snaphash_ctx* x)
 {
     if (getenv("SNAPHASH_NO_CALIBRATION")) return;
@@ -1297,18 +1409,6 @@ static void calibrate_at_init(snaphash_ctx* x)
     }
     for (hipEvent_t ev : e) if (ev) (void)hipEventDestroy(ev);
     if (!ok) (void)hipGetLastError();
-    {
-        std::vector<uint8_t> from(4u << 20, 0x3c);
-        copy_to_staging(s.h_buf, from.data(), from.size()); // warm (page tables of both sides)
-        double best = 0;
-        for (int rep = 0; rep < 2; ++rep) {
-            const double t0 = now_ms();
-            copy_to_staging(s.h_buf, from.data(), from.size());
-            const double dt = (now_ms() - t0) * 1e-3;
-            if (dt > 0 && (best == 0 || dt < best)) best = dt;
-        }
-        if (best > 0) x->calib.observe_fill(false, (double)from.size(), best);
-    }
 }
 
 int snaphash_init(const snaphash_config* cfg, snaphash_ctx** out)
@@ -1468,7 +1568,7 @@ try {
             if (!mine.empty()) c->pool.configure(256, mine);
         }
     }
-    for (auto& d : x->dev) d->owner = x.get();
+    for (auto& d : x->dev) { d->owner = x.get(); d->owner_cpus_per_engine = std::max(1u, ncpu / (unsigned)x->dev.size()); }
     if (!x->gpu_only) calibrate_at_init(x.get()); // a ctx that may plan measures the box it plans for (planner.h PlanCalib)
     *out = x.release();
     return SNAPHASH_OK;
@@ -1601,12 +1701,27 @@ static int tree_impl(snaphash_ctx* x, const char* build_dir, const char* data_ta
         if (r.is_regular) { paths.push_back(r.path.c_str()); sizes.push_back(r.size); } // info.Size() of the walk's Lstat (build.go:240-252)
     std::vector<uint8_t> dig(paths.size() * 64 + 64);
     const double th0 = now_ms();
+    // The YAML of a large tree is written WHILE its files are hashed (round 5): everything but the digests is known after
+    // the walk, so one background thread writes the document with zeros where the digests go (2 ms for 10 100 records,
+    // inside a pass of 190), and what is left behind the last kernel is the hex of the digests (~0.15 ms) instead of the
+    // whole emitter (0.7-1.4 ms).  A small tree is written afterwards as before: a thread costs more than its YAML.
+    const bool early_yaml = recs.size() >= 2048;
+    YamlSkeleton sk;
+    int sk_rc = SNAPHASH_OK;
+    ThreadJoiner skt;
+    if (early_yaml) skt.spawn([&recs, &sk, &sk_rc] { sk_rc = emit_yaml_skeleton(recs, sk, 1); });
     rc = hash_paths(x, paths.data(), paths.size(), sizes.data(), dig.data(), nullptr);
+    skt.join_all();
     const double th1 = now_ms();
     if (rc) return rc;
     const uint8_t* arch = data_tar ? dig.data() : archive_digest;
     const uint8_t* files = data_tar ? dig.data() + 64 : dig.data();
-    rc = emit_yaml(recs, arch, files, yaml);
+    if (early_yaml) {
+        rc = sk_rc;
+        if (!rc) { yaml_fill_digests(sk, arch, files); yaml.swap(sk.text); }
+    } else {
+        rc = emit_yaml(recs, arch, files, yaml);
+    }
     static const bool trace_tree = getenv("SNAPHASH_TRACE_TREE") != nullptr;
     if (trace_tree)
         fprintf(stderr, "snaphash tree: walk %.1f ms (%zu records), hash %.1f ms (%zu streams), yaml %.1f ms (%zu bytes)\n", tw1 - tw0,
@@ -1768,6 +1883,13 @@ struct snaphash_shard {
     uint32_t local_ranks = 0; // ranks that share this node's cores, as the caller said (0 = not said)
     size_t rows = 1;
     uint64_t my_bytes = 0;
+    // hashes.yaml less its digests, written by a background thread from the end of the plan on (a large tree): behind the
+    // all-gather rank 0 only has the digests' hex left to write
+    YamlSkeleton sk;
+    int sk_rc = SNAPHASH_OK;
+    bool sk_used = false;
+    std::thread sk_thread;
+    ~snaphash_shard() { if (sk_thread.joinable()) sk_thread.join(); }
 };
 
 int snaphash_shard_plan(const char* build_dir, const char* data_tar, uint32_t rank, uint32_t world, snaphash_shard** out)
@@ -1810,6 +1932,15 @@ try {
             sh->my_sizes.push_back(i == 0 ? -1 : sh->all_sizes[i]); // the archive's length is taken when it is read, like snaphash_tree
             sh->my_bytes += lens[i];
         }
+    if (sh->recs.size() >= 2048) { // (recs is not touched again; a thread that cannot be had just means the YAML is written at emit)
+        snaphash_shard* p = sh.get();
+        try {
+            sh->sk_thread = std::thread([p] {
+                try { p->sk_rc = emit_yaml_skeleton(p->recs, p->sk, 1); } catch (...) { p->sk_rc = SNAPHASH_ENOMEM; }
+            });
+            sh->sk_used = true;
+        } catch (...) { sh->sk_used = false; }
+    }
     static const bool trace_tree = getenv("SNAPHASH_TRACE_TREE") != nullptr;
     if (trace_tree)
         fprintf(stderr, "snaphash shard plan: walk %.2f ms (%zu records), names + lists + LPT over %u ranks %.2f ms\n", tp1 - tp0, sh->recs.size(), world, now_ms() - tp1);
@@ -1869,16 +2000,28 @@ try {
     return SNAPHASH_ENOMEM;
 }
 
-int snaphash_shard_emit(const snaphash_shard* sh, const uint8_t* slabs, char** yaml_out, size_t* yaml_len)
+int snaphash_shard_emit(const snaphash_shard* sh_c, const uint8_t* slabs, char** yaml_out, size_t* yaml_len)
 try {
-    if (!sh || !slabs || !yaml_out) return SNAPHASH_EINVAL;
+    if (!sh_c || !slabs || !yaml_out) return SNAPHASH_EINVAL;
+    snaphash_shard* sh = const_cast<snaphash_shard*>(sh_c); // (the skeleton's thread is joined here: the handle is not shared between threads, snaphash.h)
     *yaml_out = nullptr;
     const size_t n = sh->all_paths.size();
     std::vector<uint8_t> dig(n * 64);
     for (size_t i = 0; i < n; ++i)
         memcpy(dig.data() + 64 * i, slabs + ((size_t)sh->shard_of[i] * sh->rows + sh->row_of[i]) * 64, 64);
     std::string y;
-    const int rc = emit_yaml(sh->recs, dig.data(), dig.data() + 64, y);
+    int rc;
+    if (sh->sk_used) {
+        if (sh->sk_thread.joinable()) sh->sk_thread.join();
+        rc = sh->sk_rc;
+        if (!rc) {
+            YamlSkeleton filled = sh->sk; // (emit may be called again with other slabs: the skeleton stays as it is)
+            yaml_fill_digests(filled, dig.data(), dig.data() + 64);
+            y.swap(filled.text);
+        }
+    } else {
+        rc = emit_yaml(sh->recs, dig.data(), dig.data() + 64, y);
+    }
     if (rc) return rc;
     char* p = (char*)malloc(y.size() + 1);
     if (!p) return SNAPHASH_ENOMEM;
@@ -1996,9 +2139,11 @@ static void calib_to(const PlanCalib& k, snaphash_plan_calib* c)
 
 int snaphash_calib_observe(snaphash_plan_calib* c, int what, double bytes, double seconds)
 {
-    if (!c || c->struct_size < sizeof(snaphash_plan_calib) || what < 0 || what > 2) return SNAPHASH_EINVAL;
+    if (!c || c->struct_size < sizeof(snaphash_plan_calib) || what < 0 || what > 4) return SNAPHASH_EINVAL;
     PlanCalib k = calib_of(c);
-    const bool took = what == 0 ? k.observe_dma(bytes, seconds) : k.observe_fill(what == 2, bytes, seconds);
+    bool took = true;
+    if (what >= 3) k.relax(what == 4);
+    else took = what == 0 ? k.observe_dma(bytes, seconds) : k.observe_fill(what == 2, bytes, seconds);
     calib_to(k, c);
     return took ? 1 : 0;
 }

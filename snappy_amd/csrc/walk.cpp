@@ -71,19 +71,13 @@ void list_tree(const std::string& root, std::vector<DirList>& dirs)
         const size_t hi = dirs.size();
         const unsigned T = walk_threads(hi - lo, 4);
         std::atomic<size_t> next{lo};
-        auto work = [&]() {
+        run_on_threads(T, [&](unsigned) {
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= hi) return;
                 list_dir(dirs[i]);
             }
-        };
-        {
-            ThreadJoiner th;
-            for (unsigned t = 1; t < T; ++t) th.spawn(work);
-            work();
-            th.join_all();
-        }
+        });
         for (size_t i = lo; i < hi; ++i) // the next level (dirs may reallocate: by index)
             for (size_t k = 0; k < dirs[i].kids.size(); ++k)
                 if (dirs[i].kids[k].type == DT_DIR && !dirs[i].kids[k].lstat_errno) {
@@ -185,12 +179,7 @@ int walk_entries(const char* root_c, std::vector<WalkEntry>& ents, int* err_no, 
             }
         }
     };
-    {
-        ThreadJoiner th; // joined even when a thread cannot be started (the exception then leaves through the C entry point's catch)
-        for (unsigned t = 1; t < T; ++t) th.spawn(work, t);
-        work(0);
-        th.join_all();
-    }
+    run_on_threads(T, work); // (every thread is waited for whatever happens; a worker's exception leaves through the C entry point's catch)
     if (trace) {
         const auto t2 = std::chrono::steady_clock::now();
         fprintf(stderr, "snaphash walk: listing %zu directories (readdir + sort) %.2f ms, paths + Lstat of %zu entries on %u threads %.2f ms\n", nd,

@@ -276,3 +276,39 @@ def test_bench_starts_its_own_ranks_and_fails_loudly_without_gpus():
     assert not loads.search(body)
     head = src[src.index("def main("):src.index("sys.exit(self_launch(args))")]
     assert not loads.search(head)
+
+
+def test_large_tree_yaml_written_ahead_of_its_digests(built_lib, oracle, tmp_path):
+    """Round 5: for a tree of 2 048 records or more hashes.yaml is written from the end of the plan on, by a background
+    thread, with zeros where the digests go (hostpass.cpp emit_yaml_skeleton); snaphash_shard_emit fills the digests in.
+    The bytes must be the oracle's -- odd names (quoted, folded) and empty files included -- and a second emit with other
+    slabs must not see the first one's digests."""
+    import hashlib
+    from snappy_amd.sharded import ShardedTree
+    rng = np.random.default_rng(12)
+    build = tmp_path / "build"
+    for d in range(30):
+        (build / ("dir %02d" % d if d % 7 == 0 else "d%02d" % d)).mkdir(parents=True)
+    names = []
+    for i in range(2600):
+        d = i % 30
+        dn = "dir %02d" % d if d % 7 == 0 else "d%02d" % d
+        fn = {0: "f%04d" % i, 1: "true", 2: "1e3", 3: "a: b %d" % i, 4: "x" * 90 + str(i)}[i % 5 if i % 97 == 0 else 0]
+        p = build / dn / fn
+        if p.exists():
+            fn = "f%04d" % i
+            p = build / dn / fn
+        p.write_bytes(rng.integers(0, 256, size=int(rng.integers(0, 300)), dtype=np.uint8).tobytes())
+        names.append(str(p))
+    tar = tmp_path / "data.tar.gz"
+    tar.write_bytes(b"archive bytes")
+    want = oracle.hashes_yaml(str(build), str(tar))
+    with ShardedTree(str(build), str(tar), 0, 1) as st:
+        assert st.streams == 2601
+        slab = np.zeros((st.rows, 64), dtype=np.uint8)
+        for k, p in enumerate(st.paths()):
+            slab[k] = np.frombuffer(hashlib.sha512(open(p, "rb").read()).digest(), dtype=np.uint8)
+        assert st.emit(slab) == want
+        other = st.emit(np.zeros_like(slab))
+        assert other != want and len(other) == len(want) and other.count(b"0" * 128) == 2601
+        assert st.emit(slab) == want

@@ -364,7 +364,8 @@ def test_default_configuration_plans_every_call(built_lib, oracle, tmp_path):
         got = c.sha512_buffers(bufs)
         ex = c.stats_ex()
         cpus = int(_lib.lib().snaphash_usable_cpus())  # what the host may take depends on the cores this job may keep busy
-        host_share_bound = min(0.95, cpus * 1.5e9 / (50e9 + cpus * 1.5e9) + 0.10)
+        lane_gain = c.plan_model(False)["host_lane_gain_pct"] / 100.0  # eight streams a thread in AVX-512 lanes: ~3.2 x one stream's 1.4 GB/s
+        host_share_bound = min(0.95, cpus * 1.5e9 * lane_gain / (50e9 + cpus * 1.5e9 * lane_gain) + 0.10)
         assert ex["host_bytes"] + ex["gpu_bytes"] == n << 20 and ex["gpu_bytes"] > 0, ex
         assert ex["host_bytes"] <= host_share_bound * (n << 20), (ex, cpus)
         for i in (0, 1, n // 2, n - 1):
@@ -517,7 +518,11 @@ def test_no_stream_is_left_for_the_end(built_lib):
     shares = [int(b[4]) for b in batches]
     segments = [int(b[2]) for b in batches]
     assert max(shares) <= 2 * (16 << 10), shares          # the floor from caller memory is 16 KiB: nobody ever needs more
-    assert max(segments) <= 4096 + 1 and min(segments[3:-3]) >= 3500, segments  # full batches, and all 5 000 streams within any two of them
+    # the batches between the ramp (round 5: three eighths of a batch first, 15 % more each time) and the end (the last
+    # batch is cut in two): full ones, and all 5 000 streams within any two of them
+    s_max = max(int(b[1]) for b in batches)
+    steady = [int(b[2]) for b in batches[:-3] if int(b[1]) == s_max]
+    assert len(steady) >= 8 and max(segments) <= 4096 + 1 and min(steady) >= 3500, segments
     assert int(batches[-1][5]) == 0
 
 
@@ -669,23 +674,26 @@ def test_the_plan_is_reported_beside_what_the_call_took_and_the_box_is_calibrate
     n = 1536
     blob = np.random.default_rng(6).integers(0, 256, size=(n << 20) + 4096, dtype=np.uint8)
     bufs = [blob[(i << 20) + i % 4096:((i + 1) << 20) + i % 4096] for i in range(n)]
-    with Context(flags=0) as c:
+    # (four host threads: 16 cores with eight AVX-512 lanes each would take ALL of a batch this size -- they outrun the link --
+    # and there would be no GPU part to compare a prediction with)
+    with Context(flags=0, host_threads=4) as c:
         k0 = c.calib()
         assert k0["n_dma"] == 1 and 5e9 < k0["dma"] < 200e9, k0                 # a PCIe link of some generation
-        assert k0["n_fill_mem"] == 1 and 0.5e9 < k0["fill_mem"] < 60e9, k0
+        assert k0["n_fill_mem"] == 0 and k0["n_fill_files"] == 0, k0            # fill threads are measured by the calls themselves
         m0 = c.plan_model(False)
-        assert abs(m0["gpu_link"] - k0["dma"] * 55.0 / 56.7) < 1e6 and abs(m0["fill_rate"] - k0["fill_mem"]) < 1e6
+        assert abs(m0["gpu_link"] - k0["dma"] * 55.0 / 56.7) < 1e6 and m0["fill_rate"] == 9e9
         assert m0["host_lane_gain_pct"] in (100, 320) and m0["cpus"] == _lib.lib().snaphash_usable_cpus()
+        c.sha512_buffers(bufs)  # the first staged call of a ctx also pins its staging buffers (~40 ms for 2 x 256 MiB): not the model's business
         got = c.sha512_buffers(bufs)
         ex = c.stats_ex()
         st = c.stats()
-        assert ex["gpu_bytes"] > 0 and ex["host_bytes"] + ex["gpu_bytes"] == n << 20
+        assert ex["gpu_bytes"] > 0 and ex["host_bytes"] + ex["gpu_bytes"] == n << 20, (ex, c.plan_model(False), c.calib())
         assert ex["planned_gpu_ms"] > 0 and ex["gpu_ms"] > 0 and ex["hash_ms"] >= ex["gpu_ms"] and ex["plan_ms"] < 20
         assert (ex["planned_host_ms"] > 0) == (ex["host_bytes"] > 0) and ex["planned_threads"] >= ex["host_threads_run"]
         # the prediction is a prediction: within a factor of two on any box this suite has met (bench.py flags 25 %)
-        assert 0.5 < ex["gpu_ms"] / ex["planned_gpu_ms"] < 2.0, ex
+        assert 0.5 < ex["gpu_ms"] / ex["planned_gpu_ms"] < 2.0, (ex, c.plan_model(False), c.calib())
         k1 = c.calib()
-        assert k1["n_dma"] == 2 and k1["n_fill_mem"] >= 2                       # the call was an observation
+        assert k1["n_dma"] == 3 and k1["n_fill_mem"] == 1 and k1["fill_mem"] > 1e9  # each call was an observation (fills: not a ctx's first call)
         assert 0.5 < k1["dma"] / k0["dma"] < 2.0                                # and agrees with the probe, roughly
         # the ctx's model through the host-only planner gives the ctx's plan (same streams, same model => same split)
         m1 = c.plan_model(False)
@@ -700,7 +708,7 @@ def test_the_plan_is_reported_beside_what_the_call_took_and_the_box_is_calibrate
     with Context() as c:  # GPU only: no plan, no probe, zeros where a plan would be
         c.sha512_buffers(bufs[:64])
         ex = c.stats_ex()
-        assert ex["planned_gpu_ms"] == 0 and ex["planned_threads"] == 0 and ex["gpu_ms"] > 0 and c.calib()["n_fill_mem"] <= 1
+        assert ex["planned_gpu_ms"] == 0 and ex["planned_threads"] == 0 and ex["gpu_ms"] > 0 and c.calib()["n_dma"] <= 1
     # an ABI 4 caller's shorter snaphash_stats_ex is still filled
     with Context(flags=0) as c:
         c.sha512_buffers([b"x"])
@@ -714,7 +722,7 @@ def test_the_plan_is_reported_beside_what_the_call_took_and_the_box_is_calibrate
 @pytest.mark.kernels_only("runs in a child process that names its own configuration")
 def test_host_lanes_and_kept_descriptors_share_one_budget(built_lib, oracle, tmp_path):
     """the host part opens a descriptor per lane (eight a thread) beside the descriptors the staging
-    fill keeps between batches; under a low RLIMIT_NOFILE (SNAPHASH_FLAG_KEEP_RLIMIT, soft 96) with 24 host threads the
+    fill keeps between batches; under a low RLIMIT_NOFILE (64 descriptors above what the process holds) with 24 host threads the
     two used to overrun the limit and the call failed with EMFILE where the reference's one-file-at-a-time loop
     succeeds.  Now the call divides what the limit leaves, and an open that still finds no descriptor waits for one."""
     import subprocess
@@ -723,19 +731,24 @@ def test_host_lanes_and_kept_descriptors_share_one_budget(built_lib, oracle, tmp
     build, tar = trees.make_synthetic_tree(str(tmp_path), sizes)
     want = oracle.hashes_yaml(build, tar)
     code = (
-        "import resource, sys\n"
-        "resource.setrlimit(resource.RLIMIT_NOFILE, (96, min(4096, resource.getrlimit(resource.RLIMIT_NOFILE)[1])))\n"
+        "import os, resource, sys\n"
         "sys.path.insert(0, %r)\n"
         "from snappy_amd import Context, _lib\n"
-        "with Context(staging_bytes=8 << 20, host_threads=24, flags=_lib.FLAG_KEEP_RLIMIT) as c:\n"
-        "    assert resource.getrlimit(resource.RLIMIT_NOFILE)[0] == 96\n"
-        "    y = c.tree(%r, %r)\n"
-        "    ex = c.stats_ex()\n"
-        "    assert ex['host_bytes'] > 0 and ex['gpu_bytes'] > 0, ex\n"
-        "    assert ex['host_threads_run'] <= 24\n"
-        "    paths = [l.split(None, 1)[1] for l in open(%r).read().splitlines()]\n"
-        "    d = c.sha512_files(paths)\n"   # and the same list with no GPU part worth having: all lanes, all host
-        "sys.stdout.buffer.write(y)\n" % (ROOT, build, tar, str(tmp_path / "paths.txt")))
+        "ys = []\n"
+        "for threads in (24, 2):\n"   # 24: every stream on host threads (24 x 8 lanes want 192 descriptors); 2: a GPU part beside 16 lanes
+        "    with Context(staging_bytes=8 << 20, host_threads=threads, flags=_lib.FLAG_KEEP_RLIMIT) as c:\n"
+        "        c.sha512_buffers([b'warm' * 100000] * 40)\n"   # the runtime has opened what it opens
+        "        soft = len(os.listdir('/proc/self/fd')) + 64\n"   # 64 descriptors above what the process holds
+        "        resource.setrlimit(resource.RLIMIT_NOFILE, (soft, resource.getrlimit(resource.RLIMIT_NOFILE)[1]))\n"
+        "        ys.append(c.tree(%r, %r))\n"
+        "        ex = c.stats_ex()\n"
+        "        assert ex['host_bytes'] > 0 and ex['host_threads_run'] <= threads, ex\n"
+        "        assert threads == 24 or ex['gpu_bytes'] > 0, ex\n"
+        "        paths = [l.split(None, 1)[1] for l in open(%r).read().splitlines()]\n"
+        "        d = c.sha512_files(paths)\n"
+        "        resource.setrlimit(resource.RLIMIT_NOFILE, (4096, resource.getrlimit(resource.RLIMIT_NOFILE)[1]))\n"
+        "assert ys[0] == ys[1]\n"
+        "sys.stdout.buffer.write(ys[0])\n" % (ROOT, build, tar, str(tmp_path / "paths.txt")))
     with open(str(tmp_path / "paths.txt"), "w") as f:
         for dp, _, fs in os.walk(build):
             for name in fs:

@@ -309,7 +309,74 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     uint32_t best = kDfMinMatch - 1u, bdist = 0u, left = depth;
     uint32_t cur = p;
     bool more = true;
-#if !defined(SNAPHASH_DF_BRANCHY_WALK)
+#if defined(SNAPHASH_DF_SHARED_EXTEND) && !defined(SNAPHASH_DF_BRANCHY_WALK)
+    // Round 5 experiment (make sharedext; MEASURED SLOWER, profiles/r05_deflate_experiments.txt): ONE copy of the extension
+    // per batch, shared by the lanes' survivors.  The shipped walk writes "check, extend, update" four times a batch (a
+    // copy per candidate), and a wave runs a copy whenever ANY of its lanes has a candidate that passes its check, which on
+    // prose is nearly always; 3.35 G vector instructions a launch at four cycles each are half of all SIMD cycles
+    // (profiles/r04_targz_text_pmc.json), so fewer copies looked like the lever.  Here a batch is: the four links, the four
+    // check words, the four checks (against the best the batch STARTED with: a check only ever spares work, so an older
+    // best means at most an extension that did not have to be -- the result is the serial walk's), and then a loop in
+    // which every lane extends its next survivor, in order: as many rounds as the lane with the most survivors has.  The
+    // budget is counted as the serial walk counts it: a candidate visited costs one link whether it passed its check or
+    // not, and a cut (good / nice) ends the visit of the rest.  Byte-identical output -- and 6-11 % slower on all three
+    // corpora at every depth (text 9.9 against 9.3 ms per 64 MiB at depth 32, 15.5 against 14.8 at 96): a batch's first
+    // candidates mostly pass (there is no best to check against yet), so the rounds are four anyway, each with its ballot,
+    // its bit scan and its selects on top.
+    while (more && left) {
+        uint32_t c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0, ncand = 0;
+#define SNAPHASH_DF_LINK(dst)                                                       \
+        {                                                                           \
+            const bool want_ = more && ncand < left;                                \
+            const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
+            const bool ok_ = want_ && d_ != 0u && p - (cur - d_) <= kDfMaxDist;     \
+            more = want_ ? ok_ : more;                                              \
+            cur = ok_ ? cur - d_ : cur;                                             \
+            dst = ok_ ? cur : 0u;                                                   \
+            ncand += ok_ ? 1u : 0u;                                                 \
+        }
+        SNAPHASH_DF_LINK(c0_) SNAPHASH_DF_LINK(c1_) SNAPHASH_DF_LINK(c2_) SNAPHASH_DF_LINK(c3_)
+#undef SNAPHASH_DF_LINK
+        const uint32_t off = best >= 3u ? best - 3u : 0u;
+        const uint32_t mine = d32(L, p + off);
+        const uint8_t* gb = in + (p64 - p); // the check words come through L1/L2, beside the LDS pipe (round 3)
+        const uint32_t k0 = *reinterpret_cast<const u32_unaligned*>(gb + c0_ + off), k1 = *reinterpret_cast<const u32_unaligned*>(gb + c1_ + off),
+                       k2 = *reinterpret_cast<const u32_unaligned*>(gb + c2_ + off), k3 = *reinterpret_cast<const u32_unaligned*>(gb + c3_ + off);
+        // who passes (bit k: candidate k); without a best of three bytes or more there is nothing to check yet
+        const bool chk = best >= 3u;
+        uint32_t gomask = ((!chk || k0 == mine) ? 1u : 0u) | ((!chk || k1 == mine) ? 2u : 0u) | ((!chk || k2 == mine) ? 4u : 0u) | ((!chk || k3 == mine) ? 8u : 0u);
+        gomask &= (1u << ncand) - 1u;
+        uint32_t kpos = 0; // candidates of the batch this lane has visited
+        bool open = ncand != 0u && left != 0u;
+        while (__builtin_amdgcn_ballot_w64(open) != 0ull) { // (uniform: a round of the shared extension)
+            uint32_t cand = 0, l = 0;
+            bool ext = false;
+            if (open) {
+                const uint32_t rest = gomask >> kpos;
+                const uint32_t skip = rest ? (uint32_t)__builtin_ctz(rest) : ncand - kpos; // candidates that failed their check, up to the next survivor
+                if (rest == 0u || left <= skip) { // no survivor left in the batch, or the budget ends in front of it
+                    left -= left < skip ? left : skip;
+                    open = false;
+                } else {
+                    const uint32_t sidx = kpos + skip;
+                    left -= skip + 1u;
+                    kpos = sidx + 1u;
+                    cand = sidx == 0u ? c0_ : (sidx == 1u ? c1_ : (sidx == 2u ? c2_ : c3_));
+                    ext = true;
+                }
+            }
+            if (ext) {
+                l = extend_match(L, p, cand, maxl);
+                const bool better = l > best;
+                const uint32_t cut = (l >= kDfNice || l >= maxl) ? 0u : ((l >= kDfGood && left > depth / 4u) ? depth / 4u : left);
+                bdist = better ? p - cand : bdist;
+                left = better ? cut : left;
+                best = better ? l : best;
+                open = kpos < ncand && left != 0u;
+            }
+        }
+    }
+#elif !defined(SNAPHASH_DF_BRANCHY_WALK) // the shipped walk: check, extend, update written out per candidate
     // (The inner decisions are selects, not branches: every `if` of a divergent wave costs scalar instructions for the
     // exec mask -- the kernel issued as many of those as vector instructions -- and only the ones that skip real work
     // (a link not wanted, a candidate that fails its check word, the extension) are worth them.)
@@ -398,6 +465,84 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     if (best == 3u && bdist > kDfTooFar) best = 0u;
     return best >= kDfMinMatch ? res_pack(best, bdist, byte) : res_pack(0u, 0u, byte);
 }
+
+// ---- searcher, round 5 experiment (make pairtiles): TWO tiles per wave at a time, a lane walking the chains of two
+// positions (p and p + 64) side by side.  The walk of a position is unchanged -- same links, same candidates, same
+// result -- but its dependent LDS reads (a link, the next link, ...) now have an independent twin in flight: the kernel
+// is latency-bound (a SIMD issues one instruction in ~7 cycles with its four waves: LDS holds one workgroup per CU), so
+// memory-level parallelism inside a wave is what is left to add.
+#if defined(SNAPHASH_DF_PAIR_TILES)
+__device__ __forceinline__ void search_pair(const ChunkLds& L, const uint8_t* __restrict__ in, uint64_t n_in, uint64_t pa64, uint64_t pb64, uint64_t c1,
+                                            uint32_t depth, uint32_t& ra, uint32_t& rb)
+{
+    const uint64_t p64[2] = {pa64, pb64};
+    uint32_t p[2], byte[2], maxl[2], best[2], bdist[2], left[2], cur[2], res[2];
+    bool more[2], live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        p[u] = (uint32_t)p64[u];
+        const bool inside = p64[u] < c1;
+        byte[u] = inside ? L.data[p[u] & kDataMask] : 0u;
+        maxl[u] = inside ? ((c1 - p64[u] < 258u) ? (uint32_t)(c1 - p64[u]) : 258u) : 0u;
+        live[u] = inside && maxl[u] >= kDfMinMatch && p64[u] + 3u <= n_in;
+        res[u] = inside ? res_pack(0u, 0u, byte[u]) : 0u;
+        best[u] = kDfMinMatch - 1u; bdist[u] = 0u; left[u] = live[u] ? depth : 0u; cur[u] = p[u]; more[u] = live[u];
+    }
+    const uint8_t* gb = in + (p64[0] - p[0]); // (both positions lie in one staged piece: the same base)
+    while ((more[0] && left[0]) || (more[1] && left[1])) {
+        uint32_t c[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, ncand[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool want = more[u] && ncand[u] < left[u];
+                const uint32_t d = L.ix.ring[cur[u] & kRingMask];
+                const bool ok = want && d != 0u && p[u] - (cur[u] - d) <= kDfMaxDist;
+                more[u] = want ? ok : more[u];
+                cur[u] = ok ? cur[u] - d : cur[u];
+                c[u][k] = ok ? cur[u] : 0u;
+                ncand[u] += ok ? 1u : 0u;
+            }
+        }
+        uint32_t off[2], mine[2], kw[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            off[u] = best[u] >= 3u ? best[u] - 3u : 0u;
+            mine[u] = d32(L, p[u] + off[u]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) kw[u][k] = *reinterpret_cast<const u32_unaligned*>(gb + c[u][k] + off[u]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if ((uint32_t)k < ncand[u] && left[u]) {
+                    --left[u];
+                    bool go = true;
+                    if (best[u] >= 3u) go = (off[u] == best[u] - 3u) ? (kw[u][k] == mine[u]) : (d32(L, c[u][k] + best[u] - 3u) == d32(L, p[u] + best[u] - 3u));
+                    if (go) {
+                        const uint32_t l = extend_match(L, p[u], c[u][k], maxl[u]);
+                        const bool better = l > best[u];
+                        const uint32_t cut = (l >= kDfNice || l >= maxl[u]) ? 0u : ((l >= kDfGood && left[u] > depth / 4u) ? depth / 4u : left[u]);
+                        bdist[u] = better ? p[u] - c[u][k] : bdist[u];
+                        left[u] = better ? cut : left[u];
+                        best[u] = better ? l : best[u];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (live[u]) {
+            if (best[u] == 3u && bdist[u] > kDfTooFar) best[u] = 0u;
+            res[u] = best[u] >= kDfMinMatch ? res_pack(best[u], bdist[u], byte[u]) : res_pack(0u, 0u, byte[u]);
+        }
+    }
+    ra = res[0];
+    rb = res[1];
+}
+#endif // SNAPHASH_DF_PAIR_TILES
 
 // ---- searcher, round 4 experiment (make stream; MEASURED SLOWER, profiles/r04_deflate_stream_search.txt): the lanes of a
 // wave STREAM through positions.  search_position above gives a wave one tile and the tile costs what its slowest lane
@@ -981,7 +1126,21 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
             __builtin_amdgcn_s_setprio(0);
         }
         if (chunk_step && j < nseg) {
-#if !defined(SNAPHASH_DF_STREAM_SEARCH) // a tile per wave at a time: a tile costs its slowest lane, and adjacent positions walk adjacent candidates
+#if defined(SNAPHASH_DF_PAIR_TILES) // round 5 experiment: two tiles per wave at a time (search_pair)
+            static_assert(kSegTiles % 2u == 0u, "whole pairs of tiles");
+            for (;;) {
+                uint32_t item = 0;
+                if (lane == 0u) item = atomicAdd(&L.queue[1], 1u);
+                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+                if (item >= kSegTiles / 2u) break;
+                STAMP(t_wait, while (__hip_atomic_load(&L.across_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= 2u * item + 1u) __builtin_amdgcn_s_sleep(1));
+                uint32_t ra, rb;
+                const uint64_t pa = c0 + (uint64_t)j * kDfSeg + item * 128u + lane;
+                STAMP(t_sea, search_pair(L, in, n_in, pa, pa + 64u, c1, depth, ra, rb));
+                L.res[j % 3u][item * 128u + lane] = ra;
+                L.res[j % 3u][item * 128u + 64u + lane] = rb;
+            }
+#elif !defined(SNAPHASH_DF_STREAM_SEARCH) // a tile per wave at a time: a tile costs its slowest lane, and adjacent positions walk adjacent candidates
             for (;;) {
                 uint32_t item = 0;
                 if (lane == 0u) item = atomicAdd(&L.queue[1], 1u);

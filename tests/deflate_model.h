@@ -25,6 +25,9 @@ namespace dfmodel {
 struct Params {
     uint32_t chunk = snaphash::kDfChunk, max_dist = snaphash::kDfMaxDist, depth = snaphash::kDfDepth, good = snaphash::kDfGood,
              nice = snaphash::kDfNice, too_far = snaphash::kDfTooFar, hash_bits = snaphash::kDfHashBits;
+    uint32_t hashn = 3;   // LAB: bytes the chain's hash covers (3 = shipped); 4 / 5: longer contexts, fewer and better candidates
+    uint32_t first3 = 0;  // LAB (with hashn > 3): also try the nearest earlier position with the same THREE bytes' hash (one candidate)
+    uint32_t inherit = 0; // LAB: 1 = a position takes over what is left of its predecessor's match when that is longer than its own (within a tile of 64), 2 = across the whole chunk
 };
 struct Tok { uint32_t lit, len, dist; }; // len == 0: literal
 struct Stats { uint64_t steps = 0, tile_max_steps = 0, tiles = 0, positions = 0; };
@@ -43,10 +46,27 @@ inline void parse_chunk(const uint8_t* in, size_t n_in, size_t c0, size_t c1, co
     const size_t s0 = c0 >= P.max_dist ? c0 - P.max_dist : 0;
     std::vector<uint32_t> head(1u << P.hash_bits, 0);
     std::vector<uint16_t> link(c1 - s0, 0);
-    auto hash = [&](uint32_t w) { return ((w & 0xffffffu) * 0x9E3779B1u) >> (32u - P.hash_bits); };
+    auto hash3 = [&](uint32_t w) { return ((w & 0xffffffu) * 0x9E3779B1u) >> (32u - P.hash_bits); };
+    auto hashw = [&](const uint8_t* q) -> uint32_t {
+        if (P.hashn <= 3) return hash3(ld32(q, end));
+        uint64_t w = ld32(q, end);
+        if (P.hashn >= 5) w |= (uint64_t)(q + 4 < end ? q[4] : 0) << 32;
+        if (P.hashn >= 6) w |= (uint64_t)(q + 5 < end ? q[5] : 0) << 40;
+        return (uint32_t)((w * 0x9E3779B97F4A7C15ull) >> (64u - P.hash_bits));
+    };
+    std::vector<uint32_t> head3(P.first3 ? (1u << P.hash_bits) : 0, 0);
+    std::vector<uint16_t> link3(P.first3 ? c1 - s0 : 0, 0);
     for (size_t p = s0; p < c1; ++p) {
         if (p + 3 > n_in) break;
-        const uint32_t h = hash(ld32(in + p, end));
+        if (P.first3) {
+            const uint32_t h3 = hash3(ld32(in + p, end));
+            const uint32_t q1 = head3[h3];
+            uint32_t d3 = q1 ? (uint32_t)(p - s0) + 1u - q1 : 0u;
+            if (d3 >= 65535u) d3 = 0;
+            link3[p - s0] = (uint16_t)d3;
+            head3[h3] = (uint32_t)(p - s0) + 1u;
+        }
+        const uint32_t h = hashw(in + p);
         const uint32_t q1 = head[h]; // q + 1 - s0
         uint32_t d = q1 ? (uint32_t)(p - s0) + 1u - q1 : 0u;
         if (d >= 65535u) d = 0; // 65 535 is the kernel's "first of its hash in the tile" marker
@@ -63,7 +83,14 @@ inline void parse_chunk(const uint8_t* in, size_t n_in, size_t c0, size_t c1, co
             if (maxl < snaphash::kDfMinMatch || p + 3 > n_in) continue;
             uint32_t best = snaphash::kDfMinMatch - 1, bdist = 0, left = P.depth, steps = 0;
             size_t cur = p;
-            while (left) {
+            if (P.first3 && link3[p - s0] && link3[p - s0] <= P.max_dist) {
+                const size_t c = p - link3[p - s0];
+                uint32_t l = 0;
+                while (l < maxl && in[c + l] == in[p + l]) ++l;
+                ++steps;
+                if (l > best) { best = l; bdist = (uint32_t)(p - c); }
+            }
+            while (left && best < P.nice && best < maxl) {
                 const uint32_t d = link[cur - s0];
                 if (!d) break;
                 cur -= d;
@@ -86,6 +113,12 @@ inline void parse_chunk(const uint8_t* in, size_t n_in, size_t c0, size_t c1, co
             tile_max = std::max(tile_max, steps);
         }
         if (st) { st->tile_max_steps += tile_max; st->tiles++; }
+    }
+    if (P.inherit) {
+        for (size_t i = 1; i < len; ++i) {
+            if (P.inherit == 1 && (i & 63) == 0) continue;
+            if (mlen[i - 1] >= 4 && mlen[i - 1] - 1 > mlen[i]) { mlen[i] = mlen[i - 1] - 1; mdist[i] = mdist[i - 1]; }
+        }
     }
     // the price parse
     uint32_t f_ll[snaphash::kNumLL] = {0}, f_d[snaphash::kNumD] = {0}, ntok = 0, nmatch = 0;

@@ -68,26 +68,70 @@ static int records_from_entries_impl(std::vector<WalkEntry>& ents, std::vector<R
 {
     if (ents.empty()) return SNAPHASH_OK;
     const size_t rootlen = ents[0].path.size();
-    out.reserve(out.size() + ents.size());
-    for (WalkEntry& e : ents) {
-        const char* rel = e.path.c_str() + rootlen;
-        // build.go:229: string prefix, not path component -- "/DEBIAN-extra" is skipped too;
-        // build.go:232: the root itself.  The callback returns nil (not SkipDir), so
-        // Walk still descends into DEBIAN and skips its children one by one.
-        const bool skip = rel[0] == 0 || strncmp(rel, "/DEBIAN", 7) == 0;
-        if (skip) continue;
-        char m[11];
-        if (mode_string(e.st.st_mode, m) != SNAPHASH_OK) return SNAPHASH_EMODE;
-        out.emplace_back();
-        Record& r = out.back();
-        r.name.assign(rel + 1, e.path.size() - rootlen - 1); // build.go:250
-        r.st_mode = e.st.st_mode;
-        r.is_regular = S_ISREG(e.st.st_mode); // build.go:240
-        r.size = r.is_regular ? (int64_t)e.st.st_size : 0;
-        if (steal) r.path = std::move(e.path);
-        else r.path = e.path;
-    }
+    const size_t n = ents.size();
+    // Two passes, both in ranges on a few threads when the tree is large (10 100 entries were 0.4 ms of string work on the
+    // caller's thread, a seventh of the walk): which entries the callback keeps and whether their type has a mode string
+    // (the FIRST that has none fails the pass, as the serial loop would: what lies behind it is never looked at), then the
+    // records, each at the place the count of kept entries in front of it gives.
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(8u, usable_cpus()), n / 2048));
+    std::vector<uint8_t> keep(n, 0);
+    std::vector<size_t> kept(T + 1, 0), bad(T, n);
+    auto range = [&](unsigned t, size_t& lo, size_t& hi) { lo = n * t / T; hi = n * (t + 1) / T; };
+    run_on_threads(T, [&](unsigned t) {
+        size_t lo, hi, c = 0;
+        range(t, lo, hi);
+        for (size_t i = lo; i < hi; ++i) {
+            const char* rel = ents[i].path.c_str() + rootlen;
+            // build.go:229: string prefix, not path component -- "/DEBIAN-extra" is skipped too;
+            // build.go:232: the root itself.  The callback returns nil (not SkipDir), so
+            // Walk still descends into DEBIAN and skips its children one by one.
+            if (rel[0] == 0 || strncmp(rel, "/DEBIAN", 7) == 0) continue;
+            char m[11];
+            if (mode_string(ents[i].st.st_mode, m) != SNAPHASH_OK) { bad[t] = i; break; }
+            keep[i] = 1;
+            ++c;
+        }
+        kept[t + 1] = c;
+    });
+    size_t first_bad = n;
+    for (unsigned t = 0; t < T; ++t) first_bad = std::min(first_bad, bad[t]);
+    if (first_bad < n) return SNAPHASH_EMODE; // (entries kept in front of it are of no use to anybody: the pass fails)
+    for (unsigned t = 0; t < T; ++t) kept[t + 1] += kept[t];
+    const size_t base = out.size();
+    out.resize(base + kept[T]);
+    run_on_threads(T, [&](unsigned t) {
+        size_t lo, hi;
+        range(t, lo, hi);
+        size_t at = base + kept[t];
+        for (size_t i = lo; i < hi; ++i) {
+            if (!keep[i]) continue;
+            WalkEntry& e = ents[i];
+            Record& r = out[at++];
+            r.name.assign(e.path.c_str() + rootlen + 1, e.path.size() - rootlen - 1); // build.go:250
+            r.st_mode = e.st.st_mode;
+            r.is_regular = S_ISREG(e.st.st_mode); // build.go:240
+            r.size = r.is_regular ? (int64_t)e.st.st_size : 0;
+            if (steal) r.path = std::move(e.path);
+            else r.path = e.path;
+        }
+    });
     return SNAPHASH_OK;
+}
+
+// The first record whose name the YAML emitter does not restate (yamlscalar.cpp), or recs.size(): in ranges on a few
+// threads for a large tree.
+size_t first_unemittable_name(const std::vector<Record>& recs)
+{
+    const size_t n = recs.size();
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(8u, usable_cpus()), n / 2048));
+    std::vector<size_t> bad(T, n);
+    run_on_threads(T, [&](unsigned t) {
+        for (size_t i = n * t / T; i < n * (t + 1) / T; ++i)
+            if (!name_emittable(recs[i].name)) { bad[t] = i; break; }
+    });
+    size_t first = n;
+    for (size_t b : bad) first = std::min(first, b);
+    return first;
 }
 
 int records_from_entries(const std::vector<WalkEntry>& ents, std::vector<Record>& out)

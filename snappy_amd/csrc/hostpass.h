@@ -40,6 +40,7 @@ bool plain_safe_name(const std::string& s);
 // yamlscalar.cpp: the value of `name:` as yaml.v2 writes it (plain, single- or double-quoted, folded at 80 columns)
 int yaml_append_name_scalar(const std::string& s, int column, int indent, std::string& out);
 bool name_emittable(const std::string& s);
+size_t first_unemittable_name(const std::vector<Record>& recs); // recs.size() = every name can be written
 void hex_lower(const uint8_t d[64], char out[128]);
 int emit_yaml(const std::vector<Record>& recs, const uint8_t archive_digest[64], const uint8_t* file_digests,
               std::string& out);

@@ -1692,8 +1692,8 @@ static int tree_impl(snaphash_ctx* x, const char* build_dir, const char* data_ta
     int rc = walk_tree(build_dir, recs, &en);
     const double tw1 = now_ms();
     if (rc) return fail(x, rc, rc == SNAPHASH_EIO ? std::string(build_dir) + ": " + strerror(en) : "Unknown file mode");
-    for (const Record& r : recs)
-        if (!name_emittable(r.name)) return fail(x, SNAPHASH_ENAME, "name outside what the YAML emitter restates (yamlscalar.cpp): " + r.name);
+    if (const size_t b = first_unemittable_name(recs); b < recs.size())
+        return fail(x, SNAPHASH_ENAME, "name outside what the YAML emitter restates (yamlscalar.cpp): " + recs[b].name);
     std::vector<const char*> paths;
     std::vector<int64_t> sizes;
     if (data_tar) { paths.push_back(data_tar); sizes.push_back(-1); } // element 0 = the archive, as in the Go batch shape
@@ -1906,8 +1906,7 @@ try {
     int rc = walk_tree(build_dir, sh->recs, &en);
     if (rc) { errno = en; return rc; }
     const double tp1 = now_ms();
-    for (const Record& r : sh->recs)
-        if (!name_emittable(r.name)) return SNAPHASH_ENAME;
+    if (first_unemittable_name(sh->recs) < sh->recs.size()) return SNAPHASH_ENAME;
     sh->tar_path = data_tar;
     sh->all_paths.reserve(sh->recs.size() + 1);
     sh->all_sizes.reserve(sh->recs.size() + 1);

@@ -5,6 +5,7 @@
 
 #include <dirent.h>
 #include <errno.h>
+#include <fcntl.h>
 #include <string.h>
 
 #include <stdio.h>
@@ -33,7 +34,25 @@ struct DirList {
     std::string path;
     bool open_failed = false;
     std::vector<Child> kids;
+    DIR* kept = nullptr; // the directory, still open: its entries are Lstat'ed relative to it (below)
+    DirList() = default;
+    DirList(DirList&& o) noexcept : path(std::move(o.path)), open_failed(o.open_failed), kids(std::move(o.kids)), kept(o.kept) { o.kept = nullptr; }
+    DirList& operator=(DirList&& o) noexcept
+    {
+        if (this != &o) { release(); path = std::move(o.path); open_failed = o.open_failed; kids = std::move(o.kids); kept = o.kept; o.kept = nullptr; }
+        return *this;
+    }
+    DirList(const DirList&) = delete;
+    DirList& operator=(const DirList&) = delete;
+    ~DirList() { release(); }
+    void release() { if (kept) { closedir(kept); kept = nullptr; } }
 };
+
+// Directories kept open between their listing and the Lstat of their entries: fstatat(dirfd, name) resolves ONE path
+// component where lstat(path) resolves all of them (six on the bench's tree: a quarter of an Lstat).  Only so many at a
+// time -- a descriptor each -- and a tree of more directories Lstats the rest by path as before.
+constexpr int kKeptDirs = 192;
+std::atomic<int> g_kept_dirs{0};
 
 void list_dir(DirList& dl)
 {
@@ -46,7 +65,8 @@ void list_dir(DirList& dl)
         c.type = de->d_type;
         dl.kids.push_back(std::move(c));
     }
-    closedir(d);
+    if (dl.kids.size() >= 16 && g_kept_dirs.fetch_add(1) < kKeptDirs) dl.kept = d; // (released by the walk when the entries are Lstat'ed, or by ~DirList)
+    else { if (dl.kids.size() >= 16) g_kept_dirs.fetch_sub(1); closedir(d); }
     std::sort(dl.kids.begin(), dl.kids.end(), [](const Child& a, const Child& b) { return a.name < b.name; });
     for (Child& c : dl.kids)
         if (c.type == DT_UNKNOWN) { // this filesystem does not say: look now
@@ -64,7 +84,8 @@ unsigned walk_threads(size_t items, size_t per_thread)
 // threads (a 10 000-file tree in 100 directories: ~6 ms of readdir + sort on one thread).
 void list_tree(const std::string& root, std::vector<DirList>& dirs)
 {
-    dirs.assign(1, DirList());
+    dirs.clear();
+    dirs.emplace_back();
     dirs[0].path = root;
     size_t lo = 0;
     while (lo < dirs.size()) {
@@ -173,12 +194,21 @@ int walk_entries(const char* root_c, std::vector<WalkEntry>& ents, int* err_no, 
                 e.path += c.name;
                 if (c.lstat_errno) fail(at, c.lstat_errno); // (the look-ahead of a file system that gives no types)
                 else if (c.have_st) { e.st = c.st; e.have_st = true; }
-                else if (lstat(e.path.c_str(), &e.st) != 0) fail(at, errno);
+                else if ((dl.kept ? fstatat(dirfd(dl.kept), c.name.c_str(), &e.st, AT_SYMLINK_NOFOLLOW) : lstat(e.path.c_str(), &e.st)) != 0) fail(at, errno);
                 else e.have_st = true;
                 at += 1 + (c.dir >= 0 ? count[(size_t)c.dir] : 0);
             }
         }
     };
+    struct ReleaseDirs { // the kept directories go back whatever way the walk ends
+        std::vector<DirList>& dirs;
+        ~ReleaseDirs()
+        {
+            int n = 0;
+            for (DirList& d : dirs) if (d.kept) { d.release(); ++n; }
+            g_kept_dirs.fetch_sub(n);
+        }
+    } release_dirs{dirs};
     run_on_threads(T, work); // (every thread is waited for whatever happens; a worker's exception leaves through the C entry point's catch)
     if (trace) {
         const auto t2 = std::chrono::steady_clock::now();

@@ -27,6 +27,7 @@ struct Params {
              nice = snaphash::kDfNice, too_far = snaphash::kDfTooFar, hash_bits = snaphash::kDfHashBits;
     uint32_t hashn = 3;   // LAB: bytes the chain's hash covers (3 = shipped); 4 / 5: longer contexts, fewer and better candidates
     uint32_t first3 = 0;  // LAB (with hashn > 3): also try the nearest earlier position with the same THREE bytes' hash (one candidate)
+    uint32_t via = 0;     // LAB: N > 0 = a candidate from an earlier segment within N bytes also offers ITS best match's source (what it found is older than anything left of this walk)
     uint32_t inherit = 0; // LAB: 1 = a position takes over what is left of its predecessor's match when that is longer than its own (within a tile of 64), 2 = across the whole chunk
 };
 struct Tok { uint32_t lit, len, dist; }; // len == 0: literal
@@ -97,15 +98,27 @@ inline void parse_chunk(const uint8_t* in, size_t n_in, size_t c0, size_t c1, co
                 if (p - cur > P.max_dist) break;
                 --left;
                 ++steps;
-                if (best >= 3u && ld32(in + cur + best - 3, end) != ld32(in + p + best - 3, end)) continue;
-                uint32_t l = 0;
-                while (l < maxl && in[cur + l] == in[p + l]) ++l;
-                if (l > best) {
-                    best = l;
-                    bdist = (uint32_t)(p - cur);
-                    if (l >= P.nice || l >= maxl) break;
-                    if (l >= P.good && left > P.depth / 4) left = P.depth / 4;
+                bool stop = false;
+                for (int hop = 0; hop < (P.via ? 2 : 1) && !stop; ++hop) {
+                    size_t c = cur;
+                    if (hop == 1) { // the candidate's own best match, if its result is still at hand: an earlier segment of this chunk, not too far back
+                        const size_t seg_p = c0 + ((p - c0) / snaphash::kDfSeg) * snaphash::kDfSeg;
+                        if (cur < c0 || cur >= seg_p || p - cur > P.via || mlen[cur - c0] < 3) break;
+                        c = cur - mdist[cur - c0];
+                        if (p - c > P.max_dist) break;
+                        ++steps;
+                    }
+                    if (best >= 3u && ld32(in + c + best - 3, end) != ld32(in + p + best - 3, end)) continue;
+                    uint32_t l = 0;
+                    while (l < maxl && in[c + l] == in[p + l]) ++l;
+                    if (l > best) {
+                        best = l;
+                        bdist = (uint32_t)(p - c);
+                        if (l >= P.nice || l >= maxl) { stop = true; break; }
+                        if (l >= P.good && left > P.depth / 4) left = P.depth / 4;
+                    }
                 }
+                if (stop) break;
             }
             if (best == 3 && bdist > P.too_far) best = 0;
             if (best >= snaphash::kDfMinMatch) { mlen[i] = best; mdist[i] = bdist; }

@@ -134,7 +134,7 @@ int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
     Opt o;
-    unsigned v2 = 0, good = snaphash::kDfGood, inherit = 0, hashn = 3, first3 = 0;
+    unsigned v2 = 0, good = snaphash::kDfGood, inherit = 0, hashn = 3, first3 = 0, via = 0;
     for (int a = 2; a < argc; ++a) {
         char k[32]; unsigned v;
         if (sscanf(argv[a], "%31[^=]=%u", k, &v) != 2) return 2;
@@ -143,6 +143,7 @@ int main(int argc, char** argv)
         if (key == "good") { good = v; continue; }
         if (key == "inherit") { inherit = v; continue; }
         if (key == "hashn") { hashn = v; continue; }
+        if (key == "via") { via = v; continue; }
         if (key == "first3") { first3 = v; continue; }
         if (key == "chunk") o.chunk = v; else if (key == "seed") o.seed = v; else if (key == "hb") o.hb = v; else if (key == "ways") o.ways = v;
         else if (key == "chain") o.chain = v; else if (key == "hb2") o.hb2 = v; else if (key == "lazy") o.lazy = v; else if (key == "min") o.minm = v;
@@ -162,7 +163,7 @@ int main(int argc, char** argv)
     if (v2) { // the shipped parse (tests/deflate_model.h) with the given parameters
         dfmodel::Params P;
         P.chunk = v2p.chunk; P.max_dist = v2p.maxdist; P.depth = v2p.chain ? v2p.chain : P.depth; P.nice = v2p.nice; P.too_far = v2p.toofar;
-        P.hash_bits = v2p.hb; P.good = good; P.inherit = inherit; P.hashn = hashn; P.first3 = first3;
+        P.hash_bits = v2p.hb; P.good = good; P.inherit = inherit; P.hashn = hashn; P.first3 = first3; P.via = via;
         dfmodel::Stats st;
         uint64_t bits = 80;
         int kinds[3] = {0, 0, 0};

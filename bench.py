@@ -667,7 +667,16 @@ def self_launch(args):
                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import signal
     import threading
+
+    def pass_on(signum, frame):  # the parent is told to stop (a driver's time limit): so are the ranks, by their exact PIDs
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        raise SystemExit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, pass_on)
     out0 = []
     reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
     reader.start()

@@ -441,7 +441,8 @@ int snaphash_get_plan_model(const snaphash_ctx *ctx, int from_files, snaphash_pl
 /* ABI 5, host-only: the calibration's update rule by itself (what a ctx applies after each staged call): an observation
  * of `bytes` moved in `seconds` -- what = 0: an engine's H2D copies (HIP event time), 1: one fill thread from memory,
  * 2: one fill thread preading files (wall x threads); 3 / 4: a call that went to host threads whole measured no fill from
- * memory / files, and the estimate moves a quarter of the way back to the model's default (bytes and seconds unused).
+ * memory / files, and the estimate moves a quarter of the way back to the model's default (bytes and seconds unused);
+ * 5: a host part planned at `bytes` SECONDS took `seconds` (busiest thread): the host rate's correction, 0.6 .. 1.6.
  * Returns 1 when the observation was taken, 0 when it was too small or implausible to mean anything, negative on bad
  * arguments.  How far an observation is believed: the link within a factor of four of the defaults' 56.7 GB/s, a fill
  * thread down to half of its default and never above it (planner.h).  snaphash_calib_apply writes the calibrated
@@ -451,6 +452,8 @@ typedef struct snaphash_plan_calib {
     uint32_t n_dma, n_fill_mem, n_fill_files; /* observations taken */
     double dma;           /* B/s, 0 = not measured */
     double fill_mem, fill_files;
+    double host_gain;     /* what host threads really did over what the model said (x the model's host rate); 0 = not measured */
+    uint32_t n_host, reserved;
 } snaphash_plan_calib;
 int snaphash_calib_observe(snaphash_plan_calib *calib, int what, double bytes, double seconds);
 int snaphash_calib_apply(const snaphash_plan_calib *calib, snaphash_plan_model *model);

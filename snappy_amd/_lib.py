@@ -78,7 +78,7 @@ class PlanModel(ctypes.Structure):
 class PlanCalib(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("n_dma", ctypes.c_uint32), ("n_fill_mem", ctypes.c_uint32),
                 ("n_fill_files", ctypes.c_uint32), ("dma", ctypes.c_double), ("fill_mem", ctypes.c_double),
-                ("fill_files", ctypes.c_double)]
+                ("fill_files", ctypes.c_double), ("host_gain", ctypes.c_double), ("n_host", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class Stats(ctypes.Structure):

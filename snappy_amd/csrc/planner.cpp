@@ -55,6 +55,15 @@ bool PlanCalib::observe_fill(bool files, double bytes, double thread_seconds)
     return files ? take(fill_files, n_fill_files, cut, 0.05e9, 200e9) : take(fill_mem, n_fill_mem, cut, 0.05e9, 200e9);
 }
 
+bool PlanCalib::observe_host(double planned_s, double actual_s)
+{
+    if (planned_s < 5e-3 || actual_s < 5e-3) return false;
+    const double g = host_gain > 0 ? host_gain : 1.0;
+    const double seen = g * planned_s / actual_s; // the gain that would have made the plan come true
+    if (!(seen > 0.1 && seen < 10.0)) return false;
+    return take(host_gain, n_host, std::min(1.6, std::max(0.6, seen)), 0.1, 10.0);
+}
+
 void PlanCalib::relax(bool files)
 {
     double& est = files ? fill_files : fill_mem;
@@ -73,6 +82,7 @@ void PlanCalib::apply(PlanModel& m) const
 {
     if (m.gpu_link <= 0 && dma > 0)
         m.gpu_link = std::min(4.0 * 56.7e9, std::max(0.25 * 56.7e9, dma)) * (m.from_files ? kLinkOfDmaFiles : kLinkOfDmaMem);
+    if (host_gain > 0) m.host_rate *= std::min(1.6, std::max(0.6, host_gain));
     if (m.fill_rate <= 0) {
         const double dflt = m.from_files ? 6.5e9 : 9e9;
         const double seen = m.from_files ? fill_files : fill_mem;

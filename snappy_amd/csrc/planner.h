@@ -44,11 +44,16 @@ struct PlanCalib {
     double dma = 0;         // B/s one engine's H2D copies run at (HIP events); 0 = not measured: the model's default link
     double fill_mem = 0;    // B/s ONE fill thread copies from caller memory into pinned staging
     double fill_files = 0;  // B/s ONE fill thread preads from the page cache into pinned staging
-    unsigned n_dma = 0, n_fill_mem = 0, n_fill_files = 0; // observations taken
+    double host_gain = 0;   // what a host thread REALLY did over what the model said it would (both with the gain in force then): x the model's
+                            // host rate; 0 = not measured (1.0).  The lane gain of the eight-stream hasher (2.4 files / 3.2 memory) is one box's
+                            // number and conservative there: the C2 tree's host part was planned at 147 ms and took 130
+    unsigned n_dma = 0, n_fill_mem = 0, n_fill_files = 0, n_host = 0; // observations taken
     // an observation: bytes moved in `seconds` (link: summed event time of the copies; fill: wall x threads at it).
     // Too small to mean anything (under 4 MiB, under 50 us) or outside what any box does: ignored (returns false).
     bool observe_dma(double bytes, double seconds);
     bool observe_fill(bool files, double bytes, double thread_seconds);
+    // a host part that was planned at planned_s took actual_s (busiest thread): parts under 5 ms say nothing
+    bool observe_host(double planned_s, double actual_s);
     // A call that was planned onto host threads whole measured no fill: a low estimate that caused that plan would never be
     // corrected.  Such a call moves the estimate a quarter of the way back to the model's default, so that the GPU part is
     // tried again -- and measured again -- after a few of them.

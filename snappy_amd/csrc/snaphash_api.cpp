@@ -1203,6 +1203,13 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
     for (double b : hbusy) x->ex.host_ms = std::max(x->ex.host_ms, b);
     for (double b : gbusy) x->ex.gpu_ms = std::max(x->ex.gpu_ms, b);
     x->ex.host_threads_run = nh;
+    // what the host threads of THIS box do against what the model said -- unless the call as a whole took three times its plan:
+    // whatever happened there (a cold page cache, a neighbour on the box) is not what the next call will meet
+    if (!x->gpu_only && x->ex.planned_host_ms > 0 && !herr.load() &&
+        now_ms() - t_hash0 <= 3.0 * std::max(x->ex.planned_host_ms, x->ex.planned_gpu_ms)) {
+        std::lock_guard<std::mutex> lk(x->calib_mu);
+        x->calib.observe_host(x->ex.planned_host_ms * 1e-3, x->ex.host_ms * 1e-3);
+    }
 
     // first error (lowest walk index) fails the call, as the reference's loop would (build.go:242-244)
     int64_t bad = -1;
@@ -2128,20 +2135,23 @@ static PlanCalib calib_of(const snaphash_plan_calib* c)
     PlanCalib k;
     k.dma = c->dma; k.fill_mem = c->fill_mem; k.fill_files = c->fill_files;
     k.n_dma = c->n_dma; k.n_fill_mem = c->n_fill_mem; k.n_fill_files = c->n_fill_files;
+    k.host_gain = c->host_gain; k.n_host = c->n_host;
     return k;
 }
 static void calib_to(const PlanCalib& k, snaphash_plan_calib* c)
 {
     c->dma = k.dma; c->fill_mem = k.fill_mem; c->fill_files = k.fill_files;
     c->n_dma = k.n_dma; c->n_fill_mem = k.n_fill_mem; c->n_fill_files = k.n_fill_files;
+    c->host_gain = k.host_gain; c->n_host = k.n_host; c->reserved = 0;
 }
 
 int snaphash_calib_observe(snaphash_plan_calib* c, int what, double bytes, double seconds)
 {
-    if (!c || c->struct_size < sizeof(snaphash_plan_calib) || what < 0 || what > 4) return SNAPHASH_EINVAL;
+    if (!c || c->struct_size < sizeof(snaphash_plan_calib) || what < 0 || what > 5) return SNAPHASH_EINVAL;
     PlanCalib k = calib_of(c);
     bool took = true;
-    if (what >= 3) k.relax(what == 4);
+    if (what == 5) took = k.observe_host(bytes, seconds);
+    else if (what >= 3) k.relax(what == 4);
     else took = what == 0 ? k.observe_dma(bytes, seconds) : k.observe_fill(what == 2, bytes, seconds);
     calib_to(k, c);
     return took ? 1 : 0;

@@ -333,3 +333,25 @@ def test_abi4_sized_structs_are_still_taken(built_lib):
     assert _lib.lib().snaphash_plan_streams(arr, 3, ctypes.byref(pm), None) == 0
     pm.struct_size = 8
     assert _lib.lib().snaphash_plan_streams(arr, 3, ctypes.byref(pm), None) == _lib.EINVAL
+
+
+def test_host_rate_correction_from_what_the_host_part_took(built_lib):
+    """The lane gain of the eight-stream host hasher is one box's number: a host part planned at 147 ms that took 130 says the
+    threads of this box are 13 % faster than modelled, and the next plan gives them more (the model's
+    prediction is set beside what happened, and learns from it).  Bounded (0.6 .. 1.6), parts under 5 ms say nothing."""
+    c = _calib()
+    assert _observe(c, 5, 0.002, 0.001) == 0 and c.n_host == 0
+    assert _observe(c, 5, 0.147, 0.130) == 1 and abs(c.host_gain - 147.0 / 130.0) < 1e-9
+    assert _observe(c, 5, 0.130, 0.130) == 1 and abs(c.host_gain - 147.0 / 130.0) < 1e-9   # a plan that came true changes nothing
+    assert _observe(c, 5, 0.100, 1.000) == 1 and c.host_gain >= 0.6                        # one awful call: cut, and a quarter of the way
+    k = _calib()
+    for _ in range(20):
+        _observe(k, 5, 0.100, 0.020)
+    assert abs(k.host_gain - 1.6) < 1e-9                                                   # never beyond the bound
+    # and the plan of config 2 follows: faster host threads take more of the tree
+    import ctypes
+    from snappy_amd import _lib
+    lens = [MiB] * 10001
+    _, base = _plan(lens, from_files=1, host_lane_gain_pct=240, host_rate=1.26e9)
+    _, more = _plan(lens, from_files=1, host_lane_gain_pct=240, host_rate=1.26e9 * 1.3)
+    assert more["host_bytes"] > base["host_bytes"]

@@ -36,8 +36,8 @@ try:
                     dt = (time.perf_counter() - t0) * 1e3
                     ex = c.stats_ex()
                     k = c.calib()
-                    print("  %s pass %d: %.1f ms; planned gpu %.1f host %.1f | actual gpu %.1f host %.1f hash %.1f | host streams %d of %d, threads %d | calib dma %.1f fill_mem %.2f fill_files %.2f GB/s" %
+                    print("  %s pass %d: %.1f ms; planned gpu %.1f host %.1f | actual gpu %.1f host %.1f hash %.1f | host streams %d of %d, threads %d | calib dma %.1f fill_mem %.2f fill_files %.2f GB/s host_gain %.2f" %
                           (what, rep, dt, ex["planned_gpu_ms"], ex["planned_host_ms"], ex["gpu_ms"], ex["host_ms"], ex["hash_ms"], ex["host_streams"], n + (what == "files"),
-                           ex["host_threads_run"], k["dma"] / 1e9, k["fill_mem"] / 1e9, k["fill_files"] / 1e9), flush=True)
+                           ex["host_threads_run"], k["dma"] / 1e9, k["fill_mem"] / 1e9, k["fill_files"] / 1e9, k["host_gain"]), flush=True)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)

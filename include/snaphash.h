@@ -446,7 +446,8 @@ int snaphash_get_plan_model(const snaphash_ctx *ctx, int from_files, snaphash_pl
  * Returns 1 when the observation was taken, 0 when it was too small or implausible to mean anything, negative on bad
  * arguments.  How far an observation is believed: the link within a factor of four of the defaults' 56.7 GB/s, a fill
  * thread down to half of its default and never above it (planner.h).  snaphash_calib_apply writes the calibrated
- * gpu_link / fill_rate into a model that has not set them (from_files decides which). */
+ * gpu_link / fill_rate into a model that has not set them (from_files decides which) and corrects its host_rate (1.4e9
+ * where it names none) by what host parts took. */
 typedef struct snaphash_plan_calib {
     uint32_t struct_size; /* in: sizeof(snaphash_plan_calib) */
     uint32_t n_dma, n_fill_mem, n_fill_files; /* observations taken */
@@ -478,6 +479,8 @@ uint32_t snaphash_cgroup_cpu_quota(const char *cgroup_root, const char *proc_sel
  * Every rank must have walked the SAME tree: snaphash_shard_fingerprint (ABI 5) is a 64-bit hash of the plan (names,
  * sizes, modes, who hashes what) for the caller to compare across ranks BEFORE the all-gather -- a tree that changed
  * between two ranks' walks otherwise ends in mismatched slabs or a hung collective (snappy_amd/sharded.py does it). */
+/* A shard handle is used by one thread at a time (snaphash_shard_emit joins the thread that has been writing the
+ * document since the plan). */
 typedef struct snaphash_shard snaphash_shard;
 int snaphash_shard_plan(const char *build_dir, const char *data_tar, uint32_t rank, uint32_t world, snaphash_shard **out);
 size_t snaphash_shard_rows(const snaphash_shard *sh);     /* rows of every rank's slab */

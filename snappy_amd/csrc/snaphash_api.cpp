@@ -650,7 +650,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
                 // 57 GB/s).  The link idles while the first batch is filled, and again before every batch that takes longer
                 // to fill than its predecessor takes to copy -- doubling batches (rounds 1-4: 1/8, 1/4, 1/2, 1) lose
                 // S x (2 / 75 - 1 / 57 GB/s) at every step: 3.5 ms in all on config 2, measured 3.6
-                // (profiles/r05_tree_events.txt).  A batch that grows by less than fill rate / link rate a step never
+                // (profiles/r05_tree_events_before.txt).  A batch that grows by less than fill rate / link rate a step never
                 // makes the link wait: three eighths of a batch first, 15 % more each time (tools/ramp_ab.py; profiles/r05_ramp.txt:
                 // the link idle 1.4 + 1.1 ms at the start instead of 1.0 + 4.8).
                 double f = (double)ramp_first64 / 64.0;
@@ -704,7 +704,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         std::vector<uint32_t> still, skipped, floor_still;
         still.reserve(active.size());
         // The last batch of a link-bound job: nothing overlaps its kernel, which takes what its LARGEST share takes at a
-        // stream's 44 MB/s -- 64 KiB shares: 1.5-1.7 ms behind the last copy (profiles/r05_tree_events.txt).  So the batch
+        // stream's 44 MB/s -- 64 KiB shares: 1.5-1.7 ms behind the last copy (profiles/r05_tree_events_before.txt).  So the batch
         // that would be the last leaves 16 KiB of every stream behind for one more, whose kernel is 0.4 ms.
         constexpr uint64_t kHold = 16u << 10;
         const bool hold_back = hold_back_on && !held_back && n_active0 > 2048 && total_rem <= (long double)S_share && total_rem > (long double)(8u << 20);
@@ -1134,7 +1134,10 @@ int hash_sources_top(snaphash_ctx* x, std::vector<Source>& src, uint8_t* digests
         if (getrlimit(RLIMIT_NOFILE, &rl) == 0) soft = rl.rlim_cur == RLIM_INFINITY ? 65536 : (int64_t)rl.rlim_cur;
         // what is not ours: the descriptors the process holds right now (+ a few for what it opens meanwhile), and at
         // least the reserve snaphash_init leaves an application (512, or half of a small limit)
-        const int64_t reserve = std::max<int64_t>(open_descriptors() + 16, std::min<int64_t>(512, soft / 2));
+        // (counted only where it can matter -- a listing of /proc/self/fd is tens of microseconds, and the one-file call has 200:
+        // with the limit snaphash_init leaves, 65 536 as a rule, the application's reserve covers what it holds)
+        const int64_t held = soft < 8192 ? open_descriptors() + 16 : 0;
+        const int64_t reserve = std::max<int64_t>(held, std::min<int64_t>(512, soft / 2));
         // a fill thread holds one descriptor for the length of a pread when its file's is not a kept one
         const int64_t transient = gpu_part ? (int64_t)std::min(x->d0()->fill_cap, 12u) * (int64_t)nd : 0;
         const int64_t pool = std::max<int64_t>(2, soft - reserve - transient);
@@ -2164,9 +2167,11 @@ int snaphash_calib_apply(const snaphash_plan_calib* c, snaphash_plan_model* pm)
     m.from_files = pm->from_files != 0;
     m.gpu_link = pm->gpu_link;
     m.fill_rate = pm->fill_rate;
+    if (pm->host_rate > 0) m.host_rate = pm->host_rate;
     calib_of(c).apply(m);
     pm->gpu_link = m.gpu_link;
     pm->fill_rate = m.fill_rate;
+    pm->host_rate = m.host_rate; // (the model's default, 1.4e9, where the caller named none: corrected by what host parts took)
     return SNAPHASH_OK;
 }
 

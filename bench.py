@@ -662,6 +662,10 @@ def self_launch(args):
     procs = []
     for r in range(n):
         env = dict(os.environ)
+        # (OMP_NUM_THREADS: torch.distributed.run gives its ranks 1 unless the caller says otherwise, and for a reason that was
+        # measured here -- every rank's own OpenMP pool, as wide as the box (256), spins after each small tensor operation of the
+        # collectives and burns the job's CPU quota: two ranks took 419 ms a step instead of 202, gpurun_out/r5w)
+        env.setdefault("OMP_NUM_THREADS", "1")
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SNAPHASH_BENCH_SELF_LAUNCHED": "1",
                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
@@ -756,6 +760,8 @@ def main():
     use_dist = world > 1 or force_dist
     coll_device = None if same_gpu else "cuda"
     backend = None
+    if use_dist and "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(1)  # (a launcher that did not say: N ranks x an OpenMP pool as wide as the box oversubscribe the node; see self_launch)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "gloo" if same_gpu else "nccl"

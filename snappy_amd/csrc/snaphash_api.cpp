@@ -2052,22 +2052,28 @@ int snaphash_shard_set_local_ranks(snaphash_shard* sh, uint32_t ranks_on_this_no
     return SNAPHASH_OK;
 }
 
-// FNV-1a over what every rank must agree on before the collective: the records as walked (name, mode, size), the
-// archive's size, the world and who hashes which stream into which row
+// A 64-bit hash of what every rank must agree on before the collective: the records as walked (name, mode, size), the
+// archive's size, the world and who hashes which stream into which row.  Eight bytes a step (multiply, fold): the
+// byte-at-a-time FNV-1a this began as cost a millisecond of every rank's 3 ms plan on the 10 100 records of config 2.
 uint64_t snaphash_shard_fingerprint(const snaphash_shard* sh)
 {
     if (!sh) return 0;
-    uint64_t h = 1469598103934665603ull;
-    auto mix = [&h](const void* p, size_t n) {
-        const uint8_t* b = (const uint8_t*)p;
-        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    auto mix64 = [&h](uint64_t v) {
+        h = (h ^ v) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
     };
-    auto mix64 = [&mix](uint64_t v) { mix(&v, 8); };
+    auto mix = [&mix64](const char* p, size_t n) {
+        mix64(n);
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); mix64(w); }
+        if (i < n) { uint64_t w = 0; memcpy(&w, p + i, n - i); mix64(w); }
+    };
     mix64(sh->world);
     mix64(sh->rows);
     mix64(sh->recs.size());
     for (const Record& r : sh->recs) {
-        mix(r.name.data(), r.name.size() + 1);
+        mix(r.name.data(), r.name.size());
         mix64(((uint64_t)r.st_mode << 1) | (r.is_regular ? 1u : 0u));
         mix64(r.is_regular ? (uint64_t)r.size : 0);
     }

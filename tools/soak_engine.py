@@ -19,7 +19,7 @@ tmp = tempfile.mkdtemp(prefix="snaphash_soak_", dir="/dev/shm")
 try:
     while time.time() < t_end:
         shape = rng.choice(["equal", "zipf", "tiny", "few-huge", "mixed"])
-        n = int(rng.choice([1, 2, 7, 64, 65, 300, 1250, 4097]))
+        n = int(rng.choice([1, 2, 7, 64, 65, 300, 1250, 2049, 4097, 6000]))
         if shape == "equal":
             sizes = np.full(n, int(rng.choice([0, 1, 127, 128, 129, 4096, 65536, 1 << 20])), dtype=np.int64)
         elif shape == "zipf":
@@ -39,7 +39,7 @@ try:
         staging = int(rng.choice([1 << 16, 1 << 20, 8 << 20, 32 << 20, 64 << 20, 256 << 20]))
         flags = int(rng.choice([_lib.FLAG_GPU_ONLY, _lib.FLAG_GPU_ONLY, 0]))
         devices = [0, 0] if rng.random() < 0.25 else None
-        files = rng.random() < 0.4 and n <= 1300
+        files = rng.random() < 0.4 and n <= 6200  # (round 5: file sources of more than 2 048 streams -- the cap on files begun per batch, the cut of the last batch)
         kind = "%s/%s/%s/%s" % (shape, "files" if files else "mem", "gpu" if flags else "planned", "2eng" if devices else "1eng")
         kinds[kind] = kinds.get(kind, 0) + 1
         with Context(staging_bytes=staging, flags=flags, devices=devices) as c:

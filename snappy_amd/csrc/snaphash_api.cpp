@@ -711,14 +711,19 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         if (hold_back) held_back = true;
         bool full = false;
         size_t n_new = 0;
-        for (uint32_t id : active) {
-            if (full) { skipped.push_back(id); continue; }
+        // (one division a batch, not one a stream: the engine's thread plans 4 096 segments a batch between two fills, and in
+        // the ramp nothing hides that)
+        const bool share_all = total_rem > (long double)S;
+        const long double share_ratio = share_all ? (long double)S_share / total_rem : 1.0L;
+        for (size_t ai = 0; ai < active.size(); ++ai) {
+            const uint32_t id = active[ai];
+            if (full) { skipped.insert(skipped.end(), active.begin() + (ptrdiff_t)ai, active.end()); break; } // nobody behind a full batch is looked at
             if (cap_new && done[id] == 0 && src[id].gpu_len != 0) {
                 if (n_new >= new_cap) { skipped.push_back(id); continue; } // begun by a later batch
                 ++n_new;
             }
             const uint64_t rem = src[id].gpu_len - done[id];
-            uint64_t quota = total_rem > (long double)S ? (uint64_t)((long double)rem * (long double)S_share / total_rem) : rem;
+            uint64_t quota = share_all ? (uint64_t)((long double)rem * share_ratio) : rem;
             const bool at_floor = (quota & ~(uint64_t)(kAlign - 1)) < floor_q;
             quota = std::max(quota & ~(uint64_t)(kAlign - 1), floor_q); // a multiple of 128: segments are whole blocks
             uint64_t take = rem <= quota ? rem : quota;

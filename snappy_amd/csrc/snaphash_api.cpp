@@ -1769,9 +1769,11 @@ try {
         const std::string dir = std::string(build_dir) + "/DEBIAN";
         (void)mkdir(dir.c_str(), 0755); // os.MkdirAll(debianDir, 0755), error ignored (build.go:219)
     }
+    const double t_in = now_ms();
     TOP_ENTER(x);
     std::string y;
     int rc = tree_impl(x, build_dir, data_tar, archive_digest, y);
+    const double t_impl = now_ms();
     if (!rc && write_file) rc = write_yaml_file(x, build_dir, y); // nothing is written on error (build.go:260-267)
     end_top(x, t_top0_);
     if (rc) return rc;
@@ -1783,6 +1785,9 @@ try {
         *yaml_out = p;
     }
     if (yaml_len) *yaml_len = y.size();
+    static const bool trace_tree = getenv("SNAPHASH_TRACE_TREE") != nullptr;
+    if (trace_tree)
+        fprintf(stderr, "snaphash tree_ex: entry %.2f ms, the pass %.2f ms, the caller's copy of the YAML %.2f ms\n", t_top0_ - t_in, t_impl - t_top0_, now_ms() - t_impl);
     return SNAPHASH_OK;
 } catch (...) { // allocation or thread-creation failure: no C++ exception crosses the C boundary
     return SNAPHASH_ENOMEM;

@@ -749,7 +749,8 @@ def main():
     # LOCAL_RANK names the rank's GPU; a launcher that hands every rank ONE visible device (ordinal 0) is accommodated
     visible = torch.cuda.device_count()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if not same_gpu and world > 1 and visible < local_world and visible != 1:
+    self_launched = os.environ.get("SNAPHASH_BENCH_SELF_LAUNCHED") == "1"  # (our own children all see what the parent saw)
+    if not same_gpu and world > 1 and visible < local_world and (visible != 1 or self_launched):
         # (visible == 1: a launcher that hands every rank ONE device of its own; anything else would put two ranks on one
         # GPU, which RCCL refuses later and less legibly)
         raise SystemExit("%d ranks on this node but %d GPUs visible: one rank per GPU is the contract (SNAPHASH_BENCH_SAME_GPU=1 "

@@ -330,7 +330,8 @@ void run_on_threads(unsigned T, const std::function<void(unsigned)>& fn)
         p->configure(64, {});
         return p;
     }();
-    if (T <= 65 && mu.try_lock()) {
+    static const pid_t born_in = getpid(); // a forked child inherits the pool's object but none of its threads: it starts its own, per call
+    if (T <= 65 && getpid() == born_in && mu.try_lock()) {
         std::lock_guard<std::mutex> lk(mu, std::adopt_lock);
         // parallel_for hands out indices, not threads: an index is taken by whoever comes first, so give every index a
         // thread's whole share of the work -- which is what fn(t) is

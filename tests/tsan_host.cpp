@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <functional>
 #include <new>
@@ -35,6 +36,24 @@ int main(int argc, char** argv)
         for (size_t i = 0; i < dig.size(); ++i) dig[i] = (uint8_t)(i * 131u >> 3);
         std::string y;
         if (emit_yaml(recs, dig.data(), dig.data() + 64, y) != SNAPHASH_OK) return 5;
+        { // round 5: the document written ahead of its digests on a background thread while this one walks again (the helper
+          // pool is busy then: the walk falls back to threads of its own), the digests filled in afterwards -- the same bytes
+            YamlSkeleton sk;
+            int sk_rc = -1;
+            std::vector<Record> again;
+            {
+                ThreadJoiner bg;
+                bg.spawn([&] { sk_rc = emit_yaml_skeleton(recs, sk, round % 2 ? 1 : 8); });
+                int en2 = 0;
+                if (walk_tree(argv[1], again, &en2) != SNAPHASH_OK) return 20;
+                bg.join_all();
+            }
+            if (sk_rc != SNAPHASH_OK || sk.hex_at.size() != 1 + (size_t)std::count_if(recs.begin(), recs.end(), [](const Record& r) { return r.is_regular; })) return 21;
+            if (again.size() != recs.size()) return 22;
+            yaml_fill_digests(sk, dig.data(), dig.data() + 64);
+            if (sk.text != y) return 23;
+            if (first_unemittable_name(recs) != recs.size()) return 24;
+        }
         if (round == 0) {
             first = recs;
             first_yaml = y;

@@ -850,7 +850,11 @@ def main():
         rstream = torch.cuda.current_stream().cuda_stream
         rctx = Context(device=device, kernel=kern, stream=rstream, flags=_lib.FLAG_GPU_ONLY)  # the resident (roofline) pass: torch's stream
         ectx = Context(device=device, kernel=kern, flags=_lib.FLAG_GPU_ONLY)                    # the timed pass: own stream, own staging
-        plan = ShardedTree(build, tar, rank, world)
+        # N > 1: the ranks SHARE the walk (ABI 5 snaphash_shard_list / _plan_from): each walks every world-th entry of the root,
+        # two small all-gathers move the listings, every rank rebuilds the same records -- instead of `world` full walks
+        share = ({"device": coll_device, "force": force_dist} if use_dist and (world > 1 or force_dist) and os.environ.get("SNAPHASH_BENCH_FULL_WALKS") != "1"
+                 else None)
+        plan = ShardedTree(build, tar, rank, world, share_walk=share)
         my_paths = plan.paths()
         my_index = np.array([file_index_of(p, n_files) for p in my_paths], dtype=np.uint64)
         my_lens = np.ascontiguousarray(sizes[my_index.astype(np.int64)]) if len(my_paths) else np.zeros(0, dtype=np.uint64)
@@ -879,7 +883,7 @@ def main():
             if world == 1 and not force_dist:
                 last[key] = c.tree(build, tar)
                 return
-            with ShardedTree(build, tar, rank, world) as st:
+            with ShardedTree(build, tar, rank, world, share_walk=share) as st:
                 mine = st.hash(c)
                 slabs = st.gather(mine, device=coll_device)
                 if rank == 0:
@@ -1050,7 +1054,7 @@ def main():
                 "value_kind": "end_to_end (SURVEY sec. 8d-ii): walk + pread + pinned staging + H2D over PCIe + HIP kernels + "
                               "hashes.yaml, every byte hashed by the kernels; " +
                               ("snaphash_tree on one GPU" if world == 1 and not force_dist else
-                               "every rank its LPT share of the ONE tree (snaphash_shard_*), one all-gather of the slabs over %s, rank 0 writes the YAML" % coll_name) +
+                               "the ranks share the walk (every world-th entry of the root each, the listings all-gathered), every rank its LPT share of the ONE tree (snaphash_shard_*), one all-gather of the slabs over %s, rank 0 writes the YAML" % coll_name) +
                               ".  The HBM-resident rate is `hbm_resident` / `roofline`, never `value`",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong",

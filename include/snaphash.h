@@ -492,6 +492,16 @@ int snaphash_shard_hash(snaphash_ctx *ctx, snaphash_shard *sh, uint8_t *slab /* 
 int snaphash_shard_emit(const snaphash_shard *sh, const uint8_t *slabs /* world * rows * 64, rank-major */,
                         char **yaml_out, size_t *yaml_len);
 void snaphash_shard_free(snaphash_shard *sh);
+/* ABI 5: the ranks SHARE the walk.  snaphash_shard_plan has every rank walk the whole tree (every Lstat issued `world`
+ * times over).  Instead: every rank calls snaphash_shard_list -- it lists the root, walks the subtrees of the root's
+ * entries i with i mod world == rank and returns what it found as a blob (malloc'd; snaphash_free) -- the caller
+ * all-gathers the blobs (their lengths first), and every rank calls snaphash_shard_plan_from with all `world` blobs in
+ * rank order: the record list is rebuilt from them in filepath.Walk's order, identical on every rank, and the handle is
+ * what snaphash_shard_plan would have returned (same fingerprint).  SNAPHASH_EMISMATCH: the ranks listed different roots.
+ * A tree whose files all sit directly in the root gains nothing (the root's entries are dealt out, not its files' bytes). */
+int snaphash_shard_list(const char *build_dir, uint32_t rank, uint32_t world, void **blob_out, size_t *blob_len);
+int snaphash_shard_plan_from(const char *build_dir, const char *data_tar, uint32_t rank, uint32_t world,
+                             const void *const *blobs, const size_t *blob_lens, snaphash_shard **out);
 int snaphash_shard_set_local_ranks(snaphash_shard *sh, uint32_t ranks_on_this_node /* 0 = as found (see above) */);
 uint64_t snaphash_shard_fingerprint(const snaphash_shard *sh);
 

@@ -35,6 +35,7 @@ EXPORTS = [
     "snaphash_shard_path", "snaphash_shard_hash", "snaphash_shard_emit", "snaphash_shard_free",
     # ABI 5
     "snaphash_shard_set_local_ranks", "snaphash_shard_fingerprint", "snaphash_get_plan_model",
+    "snaphash_shard_list", "snaphash_shard_plan_from",
     "snaphash_calib_observe", "snaphash_calib_apply", "snaphash_get_calib",
 ]
 FLAG_CHECK_GATHER, FLAG_NO_RCCL, FLAG_FORCE_GATHER, FLAG_GPU_ONLY, FLAG_NO_NUMA, FLAG_KEEP_RLIMIT = 1, 2, 4, 8, 16, 32
@@ -197,6 +198,9 @@ def lib():
     L.snaphash_numa_slice.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32, vp, sz, ctypes.POINTER(sz)]
     L.snaphash_get_engine_cpus.argtypes = [vp, ctypes.c_uint32, vp, sz, ctypes.POINTER(sz)]
     L.snaphash_plan_streams.argtypes = [u64p, sz, ctypes.POINTER(PlanModel), vp]
+    L.snaphash_shard_list.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.snaphash_shard_plan_from.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(vp), ctypes.POINTER(sz),
+                                           ctypes.POINTER(vp)]
     L.snaphash_shard_set_local_ranks.argtypes = [vp, ctypes.c_uint32]
     L.snaphash_shard_fingerprint.argtypes = [vp]
     L.snaphash_shard_fingerprint.restype = ctypes.c_uint64

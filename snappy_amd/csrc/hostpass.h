@@ -54,6 +54,14 @@ struct YamlSkeleton {
 };
 int emit_yaml_skeleton(const std::vector<Record>& recs, YamlSkeleton& out, unsigned max_threads = 8 /* 1: on the calling thread alone (a background build beside a pass that needs the cores) */);
 void yaml_fill_digests(YamlSkeleton& sk, const uint8_t archive_digest[64], const uint8_t* file_digests);
+// ---- the ranks of a one-process-per-GPU job SHARE the walk (snaphash.h, ABI 5) ----
+// shard_listing: rank r's share of the walk -- the root listed, the subtrees of the root's entries i with i mod world == r
+// walked (walk.h; nothing below an entry whose name begins with "DEBIAN": build.go:229) -- as a self-describing blob.
+// records_from_listings: all `world` blobs, in rank order, back into the records of the WHOLE tree in filepath.Walk's
+// order.  The blobs come from peer ranks, but every length in them is checked: SNAPHASH_EPARSE for anything malformed,
+// SNAPHASH_EMISMATCH when the ranks listed different roots, SNAPHASH_EMODE as the serial loop would raise it.
+int shard_listing(const char* build_dir, uint32_t rank, uint32_t world, std::string& blob, int* err_no);
+int records_from_listings(const char* build_dir, uint32_t world, const void* const* blobs, const size_t* blob_lens, std::vector<Record>& recs);
 int parse_yaml(const char* text, size_t len, ParsedHashes& out);
 bool digest_matches_hex(const uint8_t d[64], const std::string& hex);
 int lpt_assign(const uint64_t* lens, size_t n, int nshards, int32_t* shard_of);

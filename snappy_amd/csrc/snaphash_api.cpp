@@ -1912,26 +1912,17 @@ struct snaphash_shard {
     ~snaphash_shard() { if (sk_thread.joinable()) sk_thread.join(); }
 };
 
-int snaphash_shard_plan(const char* build_dir, const char* data_tar, uint32_t rank, uint32_t world, snaphash_shard** out)
-try {
-    if (!build_dir || !data_tar || !out || world == 0 || rank >= world || world > 4096) return SNAPHASH_EINVAL;
-    *out = nullptr;
-    struct stat st;
-    if (stat(data_tar, &st) != 0) return SNAPHASH_EIO; // build.go:222: a missing archive fails before the walk
-    std::unique_ptr<snaphash_shard> sh(new snaphash_shard());
-    sh->rank = rank;
-    sh->world = world;
-    int en = 0;
-    const double tp0 = now_ms();
-    int rc = walk_tree(build_dir, sh->recs, &en);
-    if (rc) { errno = en; return rc; }
-    const double tp1 = now_ms();
+// What follows the walk in a rank's plan, whoever walked: names the emitter can write, the stream list (archive first),
+// the LPT shares, this rank's members, and the thread that starts writing hashes.yaml.
+static int finish_shard_plan(std::unique_ptr<snaphash_shard>& sh, const char* data_tar, int64_t tar_size)
+{
+    const uint32_t rank = sh->rank, world = sh->world;
     if (first_unemittable_name(sh->recs) < sh->recs.size()) return SNAPHASH_ENAME;
     sh->tar_path = data_tar;
     sh->all_paths.reserve(sh->recs.size() + 1);
     sh->all_sizes.reserve(sh->recs.size() + 1);
     sh->all_paths.push_back(sh->tar_path.c_str());
-    sh->all_sizes.push_back((int64_t)st.st_size);
+    sh->all_sizes.push_back(tar_size);
     for (const Record& r : sh->recs) // (recs is not touched again: the pointers stay good)
         if (r.is_regular) { sh->all_paths.push_back(r.path.c_str()); sh->all_sizes.push_back(r.size); }
     const size_t n = sh->all_paths.size();
@@ -1960,9 +1951,80 @@ try {
             sh->sk_used = true;
         } catch (...) { sh->sk_used = false; }
     }
+    return SNAPHASH_OK;
+}
+
+int snaphash_shard_plan(const char* build_dir, const char* data_tar, uint32_t rank, uint32_t world, snaphash_shard** out)
+try {
+    if (!build_dir || !data_tar || !out || world == 0 || rank >= world || world > 4096) return SNAPHASH_EINVAL;
+    *out = nullptr;
+    struct stat st;
+    if (stat(data_tar, &st) != 0) return SNAPHASH_EIO; // build.go:222: a missing archive fails before the walk
+    std::unique_ptr<snaphash_shard> sh(new snaphash_shard());
+    sh->rank = rank;
+    sh->world = world;
+    int en = 0;
+    const double tp0 = now_ms();
+    int rc = walk_tree(build_dir, sh->recs, &en);
+    if (rc) { errno = en; return rc; }
+    const double tp1 = now_ms();
+    rc = finish_shard_plan(sh, data_tar, (int64_t)st.st_size);
+    if (rc) return rc;
     static const bool trace_tree = getenv("SNAPHASH_TRACE_TREE") != nullptr;
     if (trace_tree)
         fprintf(stderr, "snaphash shard plan: walk %.2f ms (%zu records), names + lists + LPT over %u ranks %.2f ms\n", tp1 - tp0, sh->recs.size(), world, now_ms() - tp1);
+    *out = sh.release();
+    return SNAPHASH_OK;
+} catch (...) {
+    return SNAPHASH_ENOMEM;
+}
+
+// ---- ABI 5: the ranks SHARE the walk ----------------------------------------------------------------------------------
+// snaphash_shard_plan has every rank walk the whole tree: 2.8-3.2 ms of a 30 ms step at N = 8, the same Lstat issued eight
+// times over, by 128 threads at the same dentries.  Here rank r lists the root (everybody does: one directory), walks the
+// subtrees of the root's entries i with i mod world == r (filepath.Walk's order inside each, as walk.h gives it) and writes
+// what it found into a blob; the caller all-gathers the blobs (two small collectives: lengths, then bytes) and every
+// rank rebuilds the SAME record list from them -- entry i's records come from rank i mod world's blob, in the root's
+// sorted order, which is Walk's order -- and goes on as snaphash_shard_plan does.  Anything under a root entry whose name
+// begins with "DEBIAN" is never a record (build.go:229 returns before it looks at anything) and is not walked at all.
+int snaphash_shard_list(const char* build_dir, uint32_t rank, uint32_t world, void** blob_out, size_t* blob_len)
+try {
+    if (!build_dir || !blob_out || !blob_len || world == 0 || rank >= world || world > 4096) return SNAPHASH_EINVAL;
+    *blob_out = nullptr;
+    *blob_len = 0;
+    std::string blob;
+    int en = 0;
+    const int rc = shard_listing(build_dir, rank, world, blob, &en); // hostpass.cpp
+    if (rc) { errno = en; return rc; }
+    void* p = malloc(blob.size() ? blob.size() : 1);
+    if (!p) return SNAPHASH_ENOMEM;
+    memcpy(p, blob.data(), blob.size());
+    *blob_out = p;
+    *blob_len = blob.size();
+    return SNAPHASH_OK;
+} catch (...) {
+    return SNAPHASH_ENOMEM;
+}
+
+int snaphash_shard_plan_from(const char* build_dir, const char* data_tar, uint32_t rank, uint32_t world, const void* const* blobs,
+                             const size_t* blob_lens, snaphash_shard** out)
+try {
+    if (!build_dir || !data_tar || !blobs || !blob_lens || !out || world == 0 || rank >= world || world > 4096) return SNAPHASH_EINVAL;
+    *out = nullptr;
+    struct stat st;
+    if (stat(data_tar, &st) != 0) return SNAPHASH_EIO; // build.go:222: a missing archive fails before the walk
+    const double tp0 = now_ms();
+    std::unique_ptr<snaphash_shard> sh(new snaphash_shard());
+    sh->rank = rank;
+    sh->world = world;
+    int rc = records_from_listings(build_dir, world, blobs, blob_lens, sh->recs); // hostpass.cpp
+    if (rc) return rc;
+    const double tp1 = now_ms();
+    rc = finish_shard_plan(sh, data_tar, (int64_t)st.st_size);
+    if (rc) return rc;
+    static const bool trace_tree = getenv("SNAPHASH_TRACE_TREE") != nullptr;
+    if (trace_tree)
+        fprintf(stderr, "snaphash shard plan from %u ranks' listings: records %.2f ms (%zu), names + lists + LPT %.2f ms\n", world, tp1 - tp0, sh->recs.size(), now_ms() - tp1);
     *out = sh.release();
     return SNAPHASH_OK;
 } catch (...) {

@@ -57,18 +57,26 @@ class ShardedTree:
         yaml = st.emit(st.gather(slab))      # all ranks' slabs -> hashes.yaml
     """
 
-    def __init__(self, build_dir, data_tar, rank, world, local_ranks=0):
+    def __init__(self, build_dir, data_tar, rank, world, local_ranks=0, share_walk=None):
         """local_ranks: how many of the `world` ranks share THIS node's cores (0 = the launcher's LOCAL_WORLD_SIZE, else a
-        guess from the visible GPUs): a rank plans host threads and fill threads for its share of them."""
+        guess from the visible GPUs): a rank plans host threads and fill threads for its share of them.
+        share_walk: None = every rank walks the whole tree (snaphash_shard_plan); a dict(device=None | "cuda", group=None) =
+        the ranks SHARE the walk (ABI 5 snaphash_shard_list / _plan_from): each walks the subtrees of every world-th entry
+        of the root, two small all-gathers (lengths, then bytes) move the listings, every rank rebuilds the same records."""
         import ctypes
         h = ctypes.c_void_p()
-        rc = _lib.lib().snaphash_shard_plan(build_dir.encode(), data_tar.encode(), rank, world, ctypes.byref(h))
-        self._h = h if not rc else None
-        self._plan_rc = rc
         self.rank, self.world = rank, world
         self.rows = self.count = self.streams = self.bytes = 0
         self.fingerprint = 0
         self._hash_rc = 0
+        self._h = None
+        self._force = bool(share_walk and share_walk.get("force"))  # (a one-rank rehearsal of the collectives: bench.py's SNAPHASH_BENCH_FORCE_DIST)
+        if share_walk is not None and (world > 1 or self._force):
+            rc = self._plan_shared(build_dir, data_tar, share_walk.get("device"), share_walk.get("group"), h)
+        else:
+            rc = _lib.lib().snaphash_shard_plan(build_dir.encode(), data_tar.encode(), rank, world, ctypes.byref(h))
+        self._h = h if not rc else None
+        self._plan_rc = rc
         if rc:
             if world == 1 or rc == _lib.EINVAL:  # (a bad argument is the caller's bug, not a rank's misfortune)
                 raise _lib.SnaphashError(rc, build_dir)
@@ -81,6 +89,41 @@ class ShardedTree:
         self.streams = L.snaphash_shard_streams(h)
         self.bytes = L.snaphash_shard_bytes(h)
         self.fingerprint = L.snaphash_shard_fingerprint(h)
+
+    def _plan_shared(self, build_dir, data_tar, device, group, h):
+        """The shared walk: this rank's listing, the all-gather of the listings, the plan from all of them.  A rank whose
+        listing failed says so in the first collective (a negative length) and EVERY rank raises: nobody is left waiting."""
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        L = _lib.lib()
+        blob, n = ctypes.c_void_p(), ctypes.c_size_t()
+        rc = L.snaphash_shard_list(build_dir.encode(), self.rank, self.world, ctypes.byref(blob), ctypes.byref(n))
+        try:
+            dev = device or "cpu"
+            mine = torch.tensor([rc if rc else n.value], dtype=torch.int64, device=dev)
+            lens = torch.empty(self.world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(lens, mine, group=group)
+            lens = lens.cpu().tolist()
+            bad = [(r, v) for r, v in enumerate(lens) if v < 0]
+            if bad:
+                raise _lib.SnaphashError(int(bad[0][1]), "rank %d could not list its share of %s (every rank raises: nobody is left in the collective)" % (bad[0][0], build_dir))
+            width = max(max(lens), 1)
+            buf = np.zeros(width, dtype=np.uint8)
+            if n.value:
+                buf[:n.value] = np.ctypeslib.as_array(ctypes.cast(blob, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value,))
+            t = torch.from_numpy(buf)
+            if device is not None:
+                t = t.to(device)
+            every = torch.empty(self.world * width, dtype=torch.uint8, device=t.device)
+            dist.all_gather_into_tensor(every, t, group=group)
+            every = every.cpu().numpy()
+        finally:
+            if blob:
+                L.snaphash_free(blob)
+        ptrs = (ctypes.c_void_p * self.world)(*[every.ctypes.data + r * width for r in range(self.world)])
+        sizes = (ctypes.c_size_t * self.world)(*[int(v) for v in lens])
+        return L.snaphash_shard_plan_from(build_dir.encode(), data_tar.encode(), self.rank, self.world, ptrs, sizes, ctypes.byref(h))
 
     def paths(self):
         L = _lib.lib()
@@ -108,7 +151,7 @@ class ShardedTree:
         A caller that drives the C API directly owes the same check (snaphash_shard_fingerprint)."""
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not getattr(self, "_force", False):
             return
         fp = int(self.fingerprint)
         mine = torch.tensor([self._plan_rc, self._hash_rc, self.streams, self.rows, fp & 0x7fffffff, (fp >> 31) & 0x7fffffff, fp >> 62],
@@ -133,7 +176,7 @@ class ShardedTree:
         (agree): 56 bytes a rank in front of the slabs."""
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not getattr(self, "_force", False):
             return slab
         self.agree(device=device, group=group)
         t = torch.from_numpy(slab)

@@ -95,6 +95,52 @@ int main(int argc, char** argv)
             return 13;
         }
     }
+    // The shared walk's listings (round 5: snaphash_shard_list / _plan_from, hostpass.cpp shard_listing / records_from_listings):
+    // three ranks' blobs of the tree must give the full walk's records, and 20 000 mutated sets must come back as an error
+    // or as well-formed records -- never be read past their end (this build is AddressSanitizer's).
+    int lists_ok = 0, lists_bad = 0;
+    {
+        const uint32_t world = 3;
+        std::string blob[3];
+        for (uint32_t r = 0; r < world; ++r) {
+            int e2 = 0;
+            if (shard_listing(argv[1], r, world, blob[r], &e2) != SNAPHASH_OK) return 30;
+        }
+        const void* ptr[3] = {blob[0].data(), blob[1].data(), blob[2].data()};
+        size_t len[3] = {blob[0].size(), blob[1].size(), blob[2].size()};
+        std::vector<Record> again;
+        if (records_from_listings(argv[1], world, ptr, len, again) != SNAPHASH_OK || again.size() != recs.size()) return 31;
+        for (size_t i = 0; i < recs.size(); ++i)
+            if (again[i].name != recs[i].name || again[i].path != recs[i].path || again[i].st_mode != recs[i].st_mode || again[i].size != recs[i].size ||
+                again[i].is_regular != recs[i].is_regular) return 32;
+        for (int it = 0; it < 20000; ++it) {
+            std::string m[3] = {blob[0], blob[1], blob[2]};
+            std::string& v = m[rnd() % 3];
+            const int edits = 1 + rnd() % 3;
+            for (int e = 0; e < edits && !v.empty(); ++e) {
+                const size_t pos = rnd() % v.size();
+                switch (rnd() % 5) {
+                case 0: v[pos] = (char)(rnd() & 0xff); break;
+                case 1: v.erase(pos, 1 + rnd() % 8); break;
+                case 2: v.resize(pos); break;
+                case 3: { uint32_t big = 0xfffffff0u + (uint32_t)(rnd() % 16); if (pos + 4 <= v.size()) memcpy(&v[pos & ~(size_t)3], &big, 4); break; } // a length field blown up
+                default: v.insert(pos, 1 + rnd() % 3, (char)(rnd() & 0xff)); break;
+                }
+            }
+            const void* mp[3] = {m[0].data(), m[1].data(), m[2].data()};
+            size_t ml[3] = {m[0].size(), m[1].size(), m[2].size()};
+            std::vector<Record> out;
+            const int rc = records_from_listings(argv[1], world, mp, ml, out);
+            if (rc == SNAPHASH_OK) {
+                ++lists_ok;
+                for (const Record& r : out) { char ms[11]; if (r.name.empty() || mode_string(r.st_mode, ms) != SNAPHASH_OK) return 33; }
+            } else if (rc == SNAPHASH_EPARSE || rc == SNAPHASH_EMISMATCH || rc == SNAPHASH_EMODE) {
+                ++lists_bad;
+            } else {
+                return 34;
+            }
+        }
+    }
     uint32_t mode;
     if (mode_parse("", &mode) == SNAPHASH_OK) return 10;
     std::vector<uint64_t> lens(1000);
@@ -136,6 +182,6 @@ int main(int argc, char** argv)
         if (hs == n && n && r.gpu_seconds != 0) return 20;
         ++plans;
     }
-    printf("asan driver ok: %d plans, %zu records, %d mutated documents accepted, %d rejected; %d random names emitted and read back, %d refused\n", plans, recs.size(), ok, bad, emitted, refused);
+    printf("asan driver ok: %d plans, %zu records, %d mutated documents accepted, %d rejected; %d random names emitted and read back, %d refused; %d mutated listings accepted, %d rejected\n", plans, recs.size(), ok, bad, emitted, refused, lists_ok, lists_bad);
     return 0;
 }

@@ -312,3 +312,131 @@ def test_large_tree_yaml_written_ahead_of_its_digests(built_lib, oracle, tmp_pat
         other = st.emit(np.zeros_like(slab))
         assert other != want and len(other) == len(want) and other.count(b"0" * 128) == 2601
         assert st.emit(slab) == want
+
+
+def _shared_walk_worker(rank, world, port, builds, tar, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        import hashlib
+        from snappy_amd import _lib
+        from snappy_amd.sharded import ShardedTree
+        try:
+            with ShardedTree(builds[rank], tar, rank, world, share_walk={}) as st:
+                fp, count, rows = st.fingerprint, st.count, st.rows
+                slab = np.zeros((max(st.rows, 1), 64), dtype=np.uint8)
+                for k, p in enumerate(st.paths()):
+                    slab[k] = np.frombuffer(hashlib.sha512(open(p, "rb").read()).digest(), dtype=np.uint8)
+                y = st.emit(st.gather(slab))
+            q.put((rank, "ok", y, fp, count, rows))
+        except _lib.SnaphashError as e:
+            q.put((rank, "error", str(e), e.code, 0, 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def _shared_walk_tree(tmp_path):
+    import trees
+    rng = np.random.default_rng(31)
+    sizes = [int(x) for x in rng.integers(0, 4000, size=230)] + [0, 128, 90000, 1]
+    build, tar = trees.make_synthetic_tree(str(tmp_path), sizes)
+    os.makedirs(os.path.join(build, "DEBIAN", "deep"))
+    open(os.path.join(build, "DEBIAN", "control"), "w").write("x")
+    open(os.path.join(build, "DEBIAN", "deep", "y"), "w").write("y")
+    open(os.path.join(build, "DEBIANfoo"), "w").write("skipped: a string prefix, not a path component")
+    open(os.path.join(build, "a-file-in-the-root"), "w").write("top")
+    os.makedirs(os.path.join(build, "zz", "sub", "subsub"))
+    open(os.path.join(build, "zz", "sub", "subsub", "leaf"), "w").write("leaf")
+    os.makedirs(os.path.join(build, "zz-empty"))
+    os.symlink("sub", os.path.join(build, "zz", "link-to-dir"))
+    os.symlink("nowhere", os.path.join(build, "dangling"))
+    return build, tar
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_ranks_share_the_walk_gloo(world, oracle, built_lib, tmp_path):
+    """ABI 5 snaphash_shard_list / _plan_from: rank r walks the subtrees of every world-th entry of the root, the listings are
+    all-gathered (gloo here, RCCL in bench.py), and every rank rebuilds the records of the WHOLE tree in filepath.Walk's
+    order: the plan's fingerprint is the one snaphash_shard_plan gives for a full walk, hashes.yaml the oracle's."""
+    from snappy_amd.sharded import ShardedTree
+    build, tar = _shared_walk_tree(tmp_path)
+    want = oracle.hashes_yaml(build, tar)
+    full = [ShardedTree(build, tar, r, world) for r in range(world)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_walk_worker, args=(r, world, port, [build] * world, tar, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, status, y, fp, count, rows in res:
+        assert status == "ok", (rank, y)
+        assert y == want, rank
+        assert (fp, count, rows) == (full[rank].fingerprint, full[rank].count, full[rank].rows), rank
+    for st in full:
+        st.close()
+
+
+@pytest.mark.parametrize("case", ["one rank cannot list", "the ranks see different roots"])
+def test_shared_walk_failures_reach_every_rank(case, built_lib, tmp_path):
+    import shutil
+    from snappy_amd import _lib
+    build, tar = _shared_walk_tree(tmp_path / "a")
+    if case == "one rank cannot list":
+        builds = [build, build + "-gone"]
+    else:
+        other = str(tmp_path / "b" / "build")
+        shutil.copytree(build, other, symlinks=True)
+        open(os.path.join(other, "one-more-in-the-root"), "w").write("x")
+        builds = [build, other]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_walk_worker, args=(r, 2, port, builds, tar, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, status, msg, code, *_ in res:
+        assert status == "error", (rank, msg)
+        assert code == (_lib.EIO if case == "one rank cannot list" else _lib.EMISMATCH), (rank, msg, code)
+
+
+def test_shard_plan_from_rejects_malformed_listings(built_lib, tmp_path):
+    """The listings come from peer ranks, but a truncated or foreign buffer must come back as an error, never be read past."""
+    import ctypes
+    from snappy_amd import _lib
+    build, tar = _shared_walk_tree(tmp_path)
+    L = _lib.lib()
+    blobs = []
+    for r in range(2):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        assert L.snaphash_shard_list(build.encode(), r, 2, ctypes.byref(p), ctypes.byref(n)) == 0
+        blobs.append(ctypes.string_at(p, n.value))
+        L.snaphash_free(p)
+
+    def plan(b0, b1):
+        keep = [ctypes.create_string_buffer(b0, len(b0)), ctypes.create_string_buffer(b1, len(b1))]
+        ptrs = (ctypes.c_void_p * 2)(*[ctypes.addressof(k) for k in keep])
+        sizes = (ctypes.c_size_t * 2)(len(b0), len(b1))
+        h = ctypes.c_void_p()
+        rc = L.snaphash_shard_plan_from(build.encode(), tar.encode(), 0, 2, ptrs, sizes, ctypes.byref(h))
+        if rc == 0:
+            L.snaphash_shard_free(h)
+        return rc
+    assert plan(blobs[0], blobs[1]) == 0
+    assert plan(blobs[1], blobs[0]) == _lib.EPARSE                       # a blob in another rank's place
+    assert plan(blobs[0], blobs[1][:-3]) == _lib.EPARSE                  # cut short
+    assert plan(blobs[0], blobs[1] + b"x") == _lib.EPARSE                # trailing bytes
+    assert plan(blobs[0], b"") == _lib.EPARSE
+    assert plan(b"\\xff" * len(blobs[0]), blobs[1]) == _lib.EPARSE
+    for cut in range(0, len(blobs[0]), max(1, len(blobs[0]) // 97)):      # every kind of truncation
+        assert plan(blobs[0][:cut], blobs[1]) in (_lib.EPARSE, _lib.EMISMATCH)

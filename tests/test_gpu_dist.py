@@ -80,7 +80,7 @@ def _tree_worker(rank, world, port, build, tar, q, planned):
     try:
         from snappy_amd import Context, _lib
         from snappy_amd.sharded import ShardedTree
-        with Context(device=0, flags=0 if planned else _lib.FLAG_GPU_ONLY) as ctx, ShardedTree(build, tar, rank, world, local_ranks=world) as st:
+        with Context(device=0, flags=0 if planned else _lib.FLAG_GPU_ONLY) as ctx, ShardedTree(build, tar, rank, world, local_ranks=world, share_walk={} if planned else None) as st:  # (planned: the ranks also share the walk, ABI 5)
             slab = st.hash(ctx)
             ex = ctx.stats_ex()
             y = st.emit(st.gather(slab))

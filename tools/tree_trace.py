@@ -43,5 +43,29 @@ try:
                 print("rank 0 of %d: plan %.2f ms, hash %.2f ms (%d streams, %.1f MiB = %.2f GiB/s of its own); a step of %d such ranks: >= %.2f ms = %.1f GiB/s of the tree" %
                       (shards, (t1 - t0) * 1e3, (t2 - t1) * 1e3, st.count, nbytes / 2**20, nbytes / 2**30 / (t2 - t1), shards, (t2 - t0) * 1e3,
                        total / 2**30 / (t2 - t0)), flush=True)
+        if shards > 1:  # the shared walk (ABI 5), one rank's part of it timed here: its listing, then the plan from all ranks' listings
+            import ctypes
+            L = _lib.lib()
+            blobs = []
+            for r in range(shards):
+                p, nb = ctypes.c_void_p(), ctypes.c_size_t()
+                assert L.snaphash_shard_list(build.encode(), r, shards, ctypes.byref(p), ctypes.byref(nb)) == 0
+                blobs.append(ctypes.string_at(p, nb.value))
+                L.snaphash_free(p)
+            keep = [ctypes.create_string_buffer(b, len(b)) for b in blobs]
+            ptrs = (ctypes.c_void_p * shards)(*[ctypes.addressof(k) for k in keep])
+            sizes = (ctypes.c_size_t * shards)(*[len(b) for b in blobs])
+            for rep in range(4):
+                t0 = time.perf_counter()
+                p, nb = ctypes.c_void_p(), ctypes.c_size_t()
+                assert L.snaphash_shard_list(build.encode(), 0, shards, ctypes.byref(p), ctypes.byref(nb)) == 0
+                L.snaphash_free(p)
+                t1 = time.perf_counter()
+                h = ctypes.c_void_p()
+                assert L.snaphash_shard_plan_from(build.encode(), tar.encode(), 0, shards, ptrs, sizes, ctypes.byref(h)) == 0
+                t2 = time.perf_counter()
+                L.snaphash_shard_free(h)
+                print("rank 0 of %d, shared walk: its listing %.2f ms (%d bytes), the plan from all listings %.2f ms (+ two all-gathers of %d bytes in all)" %
+                      (shards, (t1 - t0) * 1e3, len(blobs[0]), (t2 - t1) * 1e3, sum(len(b) for b in blobs)), flush=True)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)

@@ -20,6 +20,39 @@ uint64_t blocks_of(uint64_t len) { return (len >> 7) + 1; }
 
 using MinHeap = std::priority_queue<double, std::vector<double>, std::greater<double>>;
 
+// order[] = the streams longest first, equal lengths in list order (what std::stable_sort by length gives -- and took 6 of
+// the 14 ms config 5's 100 000 streams were planned in: a merge sort through an index, every compare two cache misses).
+// Large lists: a radix sort over the bits the longest length has, 11 a pass, least significant first -- stable by
+// construction, three passes for anything under 8 GiB.
+void longest_first(const uint64_t* lens, size_t n, std::vector<uint32_t>& order)
+{
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    if (n < 4096) {
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lens[a] > lens[b]; });
+        return;
+    }
+    uint64_t longest = 0;
+    for (size_t i = 0; i < n; ++i) longest = std::max(longest, lens[i]);
+    unsigned bits = 0;
+    while (bits < 64 && (longest >> bits) != 0) ++bits;
+    constexpr unsigned kDigit = 11;
+    std::vector<uint32_t> other(n);
+    std::vector<uint64_t> key(n), key_other(n); // longest - len: ascending keys = descending lengths
+    for (size_t i = 0; i < n; ++i) key[i] = longest - lens[i];
+    for (unsigned shift = 0; shift < bits; shift += kDigit) {
+        size_t count[(1u << kDigit) + 1] = {0};
+        for (size_t i = 0; i < n; ++i) ++count[((key[i] >> shift) & ((1u << kDigit) - 1u)) + 1u];
+        for (size_t d = 0; d < (1u << kDigit); ++d) count[d + 1] += count[d];
+        for (size_t i = 0; i < n; ++i) {
+            const size_t at = count[(key[i] >> shift) & ((1u << kDigit) - 1u)]++;
+            other[at] = order[i];
+            key_other[at] = key[i];
+        }
+        order.swap(other);
+        key.swap(key_other);
+    }
+}
+
 } // namespace
 
 namespace {
@@ -114,8 +147,7 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
     };
 
     std::vector<uint32_t> order(n);
-    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lens[a] > lens[b]; });
+    longest_first(lens, n, order);
     std::vector<double> suffix(n + 1, 0.0), suffix_blocks(n + 1, 0.0);
     for (size_t k = n; k-- > 0;) {
         suffix[k] = suffix[k + 1] + (double)lens[order[k]];
@@ -170,6 +202,11 @@ PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)
             const double mk = std::max({g, host_makespan, cores});
             if (mk < best * 0.98) { best = mk; best_k = k + 1; best_host = host_makespan; threads = h; } // move only for a real gain
             if (host_makespan > best) break;                                                           // H only grows from here
+            // ... and once the host threads are what the split waits for, every further stream they take only makes it wait
+            // longer (H never falls).  Without this a job with one dominant stream -- config 5: its 255 MiB head alone is the
+            // makespan from k = 1 on -- walked all 100 000 streams for every thread count: 14 ms of planning in front of a
+            // 190 ms call (profiles/r05_bench_C2_default.json configs.C5), now 33 streams a thread count.
+            if (host_makespan >= g && host_makespan >= cores) break;
         }
     }
     // A GPU part that is bound by its LINK (many similar streams: no stream dominates) gains from the host only what

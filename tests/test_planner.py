@@ -355,3 +355,39 @@ def test_host_rate_correction_from_what_the_host_part_took(built_lib):
     _, base = _plan(lens, from_files=1, host_lane_gain_pct=240, host_rate=1.26e9)
     _, more = _plan(lens, from_files=1, host_lane_gain_pct=240, host_rate=1.26e9 * 1.3)
     assert more["host_bytes"] > base["host_bytes"]
+
+
+@pytest.mark.parametrize("n", [300, 4095, 4096, 20000])
+def test_the_host_takes_the_longest_streams_and_ties_go_in_list_order(built_lib, n):
+    """Round 5: lists of 4 096 streams and more are ordered by a radix sort (config 5's 100 000 streams took 14 ms to plan
+    in front of a 190 ms call, 6 of them in a merge sort through an index).  Whatever orders the list, what moves to the
+    host threads is a PREFIX of "longest first, equal lengths in list order" -- also with a handful of distinct lengths,
+    where nearly every compare is a tie."""
+    import numpy as np
+    rng = np.random.default_rng(n)
+    shapes = {
+        "ties": rng.integers(1, 6, size=n) * (3 * MiB),                       # five distinct lengths
+        "zipf": np.maximum(1024, (2**28 / rng.permutation(np.arange(1, n + 1))).astype(np.int64)),  # config 5's shape, shuffled
+        "head": np.concatenate([[5 << 30], rng.integers(0, 1 << 16, size=n - 1)]),  # one stream of more than 32 bits of length
+    }
+    for name, lens in shapes.items():
+        on_host, r = _plan([int(x) for x in lens], from_files=0, host_rate=1.4e9, host_lane_gain_pct=240)
+        k = r["host_streams"]
+        assert sum(on_host) == k and k > 0, name
+        want = np.argsort(-lens.astype(np.float64), kind="stable")[:k]
+        assert sorted(np.flatnonzero(np.array(on_host))) == sorted(want.tolist()), name
+
+
+def test_a_dominant_stream_is_planned_as_before_by_the_shortened_search(built_lib):
+    """Config 5 (100 000 files, a 255 MiB head): from the moment the head is on a host thread it alone is the host part's
+    makespan, and once that is what the split waits for no further stream can shorten the call -- the search over thread
+    counts stops there instead of trying all 100 000 streams for each (round 5: 23 -> 2 ms in this container, 14 of a
+    203 ms call on the GPU box before).  The decision is what it was: the head and the few dozen streams the GPU would take
+    longer for than the head takes a core go to host threads, and the host part is modelled at the head's time."""
+    import numpy as np
+    from snappy_amd import synthetic
+    lens = [int(x) for x in synthetic.config_sizes("C5")[:-1]]
+    on_host, r = _plan(lens, from_files=0, host_rate=1.4e9, host_lane_gain_pct=240, fill_threads=6)
+    assert 20 <= r["host_streams"] <= 60 and on_host[int(np.argmax(lens))] == 1
+    assert r["host_seconds"] < 1.05 * max(lens) / 1.4e9 + 1e-3  # the head alone
+    assert r["gpu_seconds"] < 1.1 * r["host_seconds"]

@@ -432,6 +432,8 @@ typedef struct snaphash_plan_model {
                                     returns what it uses). */
     /* ---- ABI 5 (read when struct_size covers it) ---- */
     double fill_rate;        /* IN: B/s ONE staging-fill thread moves (0 = 9e9 from memory, 6.5e9 pread of files) */
+    double fill_per_file;    /* IN: s a stream costs a fill thread whatever its length -- for files the open and close beside the other
+                                threads' (0 = 10e-6 files, 0.3e-6 memory) */
 } snaphash_plan_model;
 int snaphash_plan_streams(const uint64_t *lens, size_t n, snaphash_plan_model *model /* in/out */, uint8_t *on_host /* n, may be NULL */);
 /* ABI 5: the model `ctx` plans a call with right now -- cores, threads, the host rate measured at init, and the link and
@@ -442,21 +444,32 @@ int snaphash_get_plan_model(const snaphash_ctx *ctx, int from_files, snaphash_pl
  * of `bytes` moved in `seconds` -- what = 0: an engine's H2D copies (HIP event time), 1: one fill thread from memory,
  * 2: one fill thread preading files (wall x threads); 3 / 4: a call that went to host threads whole measured no fill from
  * memory / files, and the estimate moves a quarter of the way back to the model's default (bytes and seconds unused);
- * 5: a host part planned at `bytes` SECONDS took `seconds` (busiest thread): the host rate's correction, 0.6 .. 1.6.
+ * 5: a host part planned at `bytes` SECONDS took `seconds` (busiest thread): the host rate's correction, 0.6 .. 1.6;
+ * 6: the fill threads spent `seconds` (wall x threads, less what the bytes took at the fill rate) on `bytes` FILES of a
+ * call of small files: what a file costs a fill thread beside the others (open, close), 0.3 .. 2 x the default 10 us.
  * Returns 1 when the observation was taken, 0 when it was too small or implausible to mean anything, negative on bad
  * arguments.  How far an observation is believed: the link within a factor of four of the defaults' 56.7 GB/s, a fill
  * thread down to half of its default and never above it (planner.h).  snaphash_calib_apply writes the calibrated
- * gpu_link / fill_rate into a model that has not set them (from_files decides which) and corrects its host_rate (1.4e9
- * where it names none) by what host parts took. */
+ * gpu_link / fill_rate / fill_per_file into a model that has not set them (from_files decides which) and corrects its
+ * host_rate (1.4e9 where it names none) by what host parts took.
+ * What a ctx observes of a call: the link only from calls whose copies average 32 MiB or more (a small copy measures
+ * its latency), the fill rate only from calls whose streams average 256 KiB or more and net of the per-file cost, the
+ * per-file cost only from calls of 256 files or more that average under 64 KiB. */
 typedef struct snaphash_plan_calib {
     uint32_t struct_size; /* in: sizeof(snaphash_plan_calib) */
     uint32_t n_dma, n_fill_mem, n_fill_files; /* observations taken */
     double dma;           /* B/s, 0 = not measured */
     double fill_mem, fill_files;
     double host_gain;     /* what host threads really did over what the model said (x the model's host rate); 0 = not measured */
-    uint32_t n_host, reserved;
+    uint32_t n_host, n_fill_per_file;
+    double fill_per_file; /* s per file on a fill thread; 0 = not measured */
 } snaphash_plan_calib;
 int snaphash_calib_observe(snaphash_plan_calib *calib, int what, double bytes, double seconds);
+/* One staged call of an engine, sorted into those observations by what it can speak about (the rule above; what a ctx does
+ * after every staged call): `bytes` of `streams` streams went over the link in `copies` copies taking `h2d_seconds`, the fill
+ * threads spent `fill_thread_seconds` (wall x threads) on them. */
+int snaphash_calib_observe_call(snaphash_plan_calib *calib, int from_files, double bytes, double streams, double copies,
+                                double h2d_seconds, double fill_thread_seconds);
 int snaphash_calib_apply(const snaphash_plan_calib *calib, snaphash_plan_model *model);
 int snaphash_get_calib(const snaphash_ctx *ctx, snaphash_plan_calib *out); /* what ctx has measured so far */
 /* CPUs this process may keep busy: affinity mask capped by the cgroup CPU quota (what host_threads = 0 plans with). */

@@ -34,7 +34,7 @@ EXPORTS = [
     "snaphash_shard_plan", "snaphash_shard_rows", "snaphash_shard_count", "snaphash_shard_streams", "snaphash_shard_bytes",
     "snaphash_shard_path", "snaphash_shard_hash", "snaphash_shard_emit", "snaphash_shard_free",
     # ABI 5
-    "snaphash_shard_set_local_ranks", "snaphash_shard_fingerprint", "snaphash_get_plan_model",
+    "snaphash_shard_set_local_ranks", "snaphash_shard_fingerprint", "snaphash_get_plan_model", "snaphash_calib_observe_call",
     "snaphash_shard_list", "snaphash_shard_plan_from",
     "snaphash_calib_observe", "snaphash_calib_apply", "snaphash_get_calib",
 ]
@@ -73,13 +73,14 @@ class PlanModel(ctypes.Structure):
                 ("gpu_latency", ctypes.c_double),
                 ("gpu_seconds", ctypes.c_double), ("host_seconds", ctypes.c_double), ("host_streams", ctypes.c_uint64),
                 ("host_bytes", ctypes.c_uint64), ("host_threads_used", ctypes.c_uint32), ("host_lane_gain_pct", ctypes.c_uint32),
-                ("fill_rate", ctypes.c_double)]  # ABI 5
+                ("fill_rate", ctypes.c_double), ("fill_per_file", ctypes.c_double)]  # ABI 5
 
 
 class PlanCalib(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("n_dma", ctypes.c_uint32), ("n_fill_mem", ctypes.c_uint32),
                 ("n_fill_files", ctypes.c_uint32), ("dma", ctypes.c_double), ("fill_mem", ctypes.c_double),
-                ("fill_files", ctypes.c_double), ("host_gain", ctypes.c_double), ("n_host", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("fill_files", ctypes.c_double), ("host_gain", ctypes.c_double), ("n_host", ctypes.c_uint32), ("n_fill_per_file", ctypes.c_uint32),
+                ("fill_per_file", ctypes.c_double)]
 
 
 class Stats(ctypes.Structure):
@@ -206,6 +207,7 @@ def lib():
     L.snaphash_shard_fingerprint.restype = ctypes.c_uint64
     L.snaphash_get_plan_model.argtypes = [vp, ctypes.c_int, ctypes.POINTER(PlanModel)]
     L.snaphash_calib_observe.argtypes = [ctypes.POINTER(PlanCalib), ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    L.snaphash_calib_observe_call.argtypes = [ctypes.POINTER(PlanCalib), ctypes.c_int] + [ctypes.c_double] * 5
     L.snaphash_calib_apply.argtypes = [ctypes.POINTER(PlanCalib), ctypes.POINTER(PlanModel)]
     L.snaphash_get_calib.argtypes = [vp, ctypes.POINTER(PlanCalib)]
     L.snaphash_usable_cpus.argtypes = []
@@ -451,7 +453,7 @@ class Context:
         pm = PlanModel(ctypes.sizeof(PlanModel))
         self._check(lib().snaphash_get_plan_model(self._h, 1 if from_files else 0, ctypes.byref(pm)))
         return {k: getattr(pm, k) for k in ("n_devices", "cpus", "fill_threads", "host_threads", "from_files", "host_rate",
-                                            "gpu_stream_rate", "gpu_link", "gpu_latency", "host_lane_gain_pct", "fill_rate")}
+                                            "gpu_stream_rate", "gpu_link", "gpu_latency", "host_lane_gain_pct", "fill_rate", "fill_per_file")}
 
     def calib(self):
         c = PlanCalib(ctypes.sizeof(PlanCalib))

@@ -88,6 +88,30 @@ bool PlanCalib::observe_fill(bool files, double bytes, double thread_seconds)
     return files ? take(fill_files, n_fill_files, cut, 0.05e9, 200e9) : take(fill_mem, n_fill_mem, cut, 0.05e9, 200e9);
 }
 
+bool PlanCalib::observe_fill_per_file(double files, double thread_seconds)
+{
+    if (files < 256 || thread_seconds <= 0) return false;
+    const double each = thread_seconds / files;
+    if (!(each >= 0.05e-6 && each <= 1e-3)) return false;
+    return take(fill_per_file, n_fill_per_file, std::min(2.0 * 10e-6, std::max(0.3 * 10e-6, each)), 0.05e-6, 1e-3);
+}
+
+void PlanCalib::observe_call(bool files, double bytes, double streams, double copies, double h2d_seconds, double fill_thread_seconds, bool take_fill)
+{
+    if (copies >= 1 && bytes / copies >= (double)(32u << 20)) observe_dma(bytes, h2d_seconds);
+    if (!take_fill || streams < 1 || bytes <= 0) return;
+    const double each = files ? (fill_per_file > 0 ? fill_per_file : 10e-6) : 0.3e-6; // what the model charges a stream
+    const double rate = files ? (fill_files > 0 ? fill_files : 6.5e9) : (fill_mem > 0 ? fill_mem : 9e9);
+    const double mean = bytes / streams;
+    if (mean >= (double)(256u << 10)) {
+        const double net = fill_thread_seconds - streams * each;
+        if (net > 0.5 * fill_thread_seconds) observe_fill(files, bytes, net);
+    } else if (files && mean < (double)(64u << 10)) {
+        const double net = fill_thread_seconds - bytes / rate;
+        if (net > 0.5 * fill_thread_seconds) observe_fill_per_file(streams, net);
+    }
+}
+
 bool PlanCalib::observe_host(double planned_s, double actual_s)
 {
     if (planned_s < 5e-3 || actual_s < 5e-3) return false;
@@ -121,6 +145,8 @@ void PlanCalib::apply(PlanModel& m) const
         const double seen = m.from_files ? fill_files : fill_mem;
         if (seen > 0) m.fill_rate = std::min(dflt, std::max(0.5 * dflt, seen));
     }
+    // what a file costs a fill thread: both ways (the descriptor table's lock is a box's own: its cores, its kernel)
+    if (m.fill_per_stream <= 0 && m.from_files && fill_per_file > 0) m.fill_per_stream = std::min(2.0 * 10e-6, std::max(0.3 * 10e-6, fill_per_file));
 }
 
 PlanResult plan_streams(const uint64_t* lens, size_t n, const PlanModel& m)

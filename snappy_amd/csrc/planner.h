@@ -47,11 +47,20 @@ struct PlanCalib {
     double host_gain = 0;   // what a host thread REALLY did over what the model said it would (both with the gain in force then): x the model's
                             // host rate; 0 = not measured (1.0).  The lane gain of the eight-stream hasher (2.4 files / 3.2 memory) is one box's
                             // number and conservative there: the C2 tree's host part was planned at 147 ms and took 130
-    unsigned n_dma = 0, n_fill_mem = 0, n_fill_files = 0, n_host = 0; // observations taken
+    double fill_per_file = 0; // s a FILE costs a fill thread whatever its length (open + close beside the other threads'); 0 = not measured (10 us)
+    unsigned n_dma = 0, n_fill_mem = 0, n_fill_files = 0, n_host = 0, n_fill_per_file = 0; // observations taken
     // an observation: bytes moved in `seconds` (link: summed event time of the copies; fill: wall x threads at it).
     // Too small to mean anything (under 4 MiB, under 50 us) or outside what any box does: ignored (returns false).
     bool observe_dma(double bytes, double seconds);
     bool observe_fill(bool files, double bytes, double thread_seconds);
+    // `files` files cost the fill threads `thread_seconds` beyond what their bytes took: 256 files or more, 0.3 .. 2 x the default 10 us
+    bool observe_fill_per_file(double files, double thread_seconds);
+    // What ONE staged call of an engine says, sorted into the observations above by what it can speak about (round 5: a tree of
+    // 5 000 x 8 KiB moved the LINK estimate to 41 GB/s -- three copies of 12 MiB measure their latency -- and the fill rate to
+    // its floor -- the threads spent their time in open(), not in bytes -- and the next big tree was planned with both):
+    // the link from copies of 32 MiB and more on average, the fill rate from streams of 256 KiB and more on average and net
+    // of the per-file cost, the per-file cost from calls of small files (under 64 KiB on average) net of their bytes.
+    void observe_call(bool files, double bytes, double streams, double copies, double h2d_seconds, double fill_thread_seconds, bool take_fill);
     // a host part that was planned at planned_s took actual_s (busiest thread): parts under 5 ms say nothing
     bool observe_host(double planned_s, double actual_s);
     // A call that was planned onto host threads whole measured no fill: a low estimate that caused that plan would never be

@@ -622,6 +622,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     double t_wait = 0, t_plan = 0, t_read = 0, t_launch = 0; // where the host side of the engine spends its time (SNAPHASH_TRACE_TREE)
     const double t_engine0 = now_ms();
     double t_first_copy = 0; // host clock: the first H2D is enqueued this long after the engine started
+    size_t n_copies = 0;     // H2D copies of this call (what its link observation is worth: planner.h PlanCalib::observe_call)
 
     while (!active.empty()) {
         const unsigned q = batch % nsub;
@@ -707,7 +708,10 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
         // stream's 44 MB/s -- 64 KiB shares: 1.5-1.7 ms behind the last copy (profiles/r05_tree_events_before.txt).  So the batch
         // that would be the last leaves 16 KiB of every stream behind for one more, whose kernel is 0.4 ms.
         constexpr uint64_t kHold = 16u << 10;
-        const bool hold_back = hold_back_on && !held_back && n_active0 > 2048 && total_rem <= (long double)S_share && total_rem > (long double)(8u << 20);
+        // (... of streams that HAVE that much left: 5 000 x 8 KiB made the batch in front of the last an empty one, every stream
+        // "all of it in the batch behind this one": profiles/r05_small_files.txt)
+        const bool hold_back = hold_back_on && !held_back && n_active0 > 2048 && total_rem <= (long double)S_share && total_rem > (long double)(8u << 20) &&
+                               total_rem > (long double)(2 * kHold) * (long double)active.size();
         if (hold_back) held_back = true;
         bool full = false;
         size_t n_new = 0;
@@ -771,6 +775,7 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
 
         if (used) { // copy stream: the slot's previous kernel was already waited for above
             if (batch == 0) t_first_copy = now_ms() - t_engine0;
+            ++n_copies;
             EventPair* ev = next_events(c, 1);
             if (!ev) return fail(c, SNAPHASH_EDEVICE, "hipEventCreate failed");
             HIP_TRY(c, hipEventRecord(ev->a, c->copy_stream));
@@ -825,13 +830,12 @@ int hash_sources(DevCtx* c, const std::vector<Source>& src, uint8_t* digests, ui
     c->stats.streams = n;
     if (c->owner) { // what this call says about the box: the copies' own rate (HIP events) and what a fill thread moved
         std::lock_guard<std::mutex> lk(c->owner->calib_mu);
-        c->owner->calib.observe_dma((double)job_bytes, c->stats.h2d_ms * 1e-3);
-        // (not the engine's first staged call: its fill threads are being created, its staging pages touched for the first time)
-        // ... nor a call that took three times what its plan said: whatever happened there (cold page cache, a neighbour on
-        // the box) is not what the next call will meet
+        // (the fill: not the engine's first staged call -- its fill threads are being created, its staging pages touched for the
+        // first time -- nor a call that took three times what its plan said: whatever happened there (cold page cache, a
+        // neighbour on the box) is not what the next call will meet)
         const double planned = c->owner->ex.planned_gpu_ms, took = now_ms() - t_engine0;
-        if (c->staged_calls++ > 0 && !(planned > 0 && took > 3.0 * planned))
-            c->owner->calib.observe_fill(!from_memory, (double)c->fill_bytes, c->fill_thread_s);
+        const bool take_fill = c->staged_calls++ > 0 && !(planned > 0 && took > 3.0 * planned);
+        c->owner->calib.observe_call(!from_memory, (double)c->fill_bytes, (double)n, (double)n_copies, c->stats.h2d_ms * 1e-3, c->fill_thread_s, take_fill);
     }
     return SNAPHASH_OK;
 }
@@ -2162,7 +2166,8 @@ try {
     constexpr uint32_t kAbi4Size = (uint32_t)offsetof(snaphash_plan_model, fill_rate);
     if (!pm || pm->struct_size < kAbi4Size || (n && !lens)) return SNAPHASH_EINVAL;
     PlanModel m;
-    if (pm->struct_size >= sizeof(snaphash_plan_model) && pm->fill_rate > 0) m.fill_rate = pm->fill_rate;
+    if (pm->struct_size >= offsetof(snaphash_plan_model, fill_per_file) && pm->fill_rate > 0) m.fill_rate = pm->fill_rate;
+    if (pm->struct_size >= sizeof(snaphash_plan_model) && pm->fill_per_file > 0) m.fill_per_stream = pm->fill_per_file;
     m.n_devices = pm->n_devices ? pm->n_devices : 1;
     m.cpus = pm->cpus ? pm->cpus : usable_cpus();
     m.from_files = pm->from_files != 0;
@@ -2205,6 +2210,7 @@ try {
     v.gpu_latency = m.gpu_latency;
     v.host_lane_gain_pct = (uint32_t)(m.host_lane_gain * 100.0 + 0.5);
     v.fill_rate = m.fill_rate > 0 ? m.fill_rate : (m.from_files ? 6.5e9 : 9e9);
+    v.fill_per_file = m.fill_per_stream > 0 ? m.fill_per_stream : (m.from_files ? 10e-6 : 0.3e-6);
     memcpy(pm, &v, have);
     return SNAPHASH_OK;
 } catch (...) {
@@ -2217,25 +2223,38 @@ static PlanCalib calib_of(const snaphash_plan_calib* c)
     k.dma = c->dma; k.fill_mem = c->fill_mem; k.fill_files = c->fill_files;
     k.n_dma = c->n_dma; k.n_fill_mem = c->n_fill_mem; k.n_fill_files = c->n_fill_files;
     k.host_gain = c->host_gain; k.n_host = c->n_host;
+    k.fill_per_file = c->fill_per_file; k.n_fill_per_file = c->n_fill_per_file;
     return k;
 }
 static void calib_to(const PlanCalib& k, snaphash_plan_calib* c)
 {
     c->dma = k.dma; c->fill_mem = k.fill_mem; c->fill_files = k.fill_files;
     c->n_dma = k.n_dma; c->n_fill_mem = k.n_fill_mem; c->n_fill_files = k.n_fill_files;
-    c->host_gain = k.host_gain; c->n_host = k.n_host; c->reserved = 0;
+    c->host_gain = k.host_gain; c->n_host = k.n_host;
+    c->fill_per_file = k.fill_per_file; c->n_fill_per_file = k.n_fill_per_file;
 }
 
 int snaphash_calib_observe(snaphash_plan_calib* c, int what, double bytes, double seconds)
 {
-    if (!c || c->struct_size < sizeof(snaphash_plan_calib) || what < 0 || what > 5) return SNAPHASH_EINVAL;
+    if (!c || c->struct_size < sizeof(snaphash_plan_calib) || what < 0 || what > 6) return SNAPHASH_EINVAL;
     PlanCalib k = calib_of(c);
     bool took = true;
-    if (what == 5) took = k.observe_host(bytes, seconds);
+    if (what == 6) took = k.observe_fill_per_file(bytes, seconds);
+    else if (what == 5) took = k.observe_host(bytes, seconds);
     else if (what >= 3) k.relax(what == 4);
     else took = what == 0 ? k.observe_dma(bytes, seconds) : k.observe_fill(what == 2, bytes, seconds);
     calib_to(k, c);
     return took ? 1 : 0;
+}
+
+int snaphash_calib_observe_call(snaphash_plan_calib* c, int from_files, double bytes, double streams, double copies, double h2d_seconds,
+                                double fill_thread_seconds)
+{
+    if (!c || c->struct_size < sizeof(snaphash_plan_calib)) return SNAPHASH_EINVAL;
+    PlanCalib k = calib_of(c);
+    k.observe_call(from_files != 0, bytes, streams, copies, h2d_seconds, fill_thread_seconds, true);
+    calib_to(k, c);
+    return SNAPHASH_OK;
 }
 
 int snaphash_calib_apply(const snaphash_plan_calib* c, snaphash_plan_model* pm)
@@ -2245,10 +2264,12 @@ int snaphash_calib_apply(const snaphash_plan_calib* c, snaphash_plan_model* pm)
     m.from_files = pm->from_files != 0;
     m.gpu_link = pm->gpu_link;
     m.fill_rate = pm->fill_rate;
+    m.fill_per_stream = pm->fill_per_file;
     if (pm->host_rate > 0) m.host_rate = pm->host_rate;
     calib_of(c).apply(m);
     pm->gpu_link = m.gpu_link;
     pm->fill_rate = m.fill_rate;
+    pm->fill_per_file = m.fill_per_stream;
     pm->host_rate = m.host_rate; // (the model's default, 1.4e9, where the caller named none: corrected by what host parts took)
     return SNAPHASH_OK;
 }

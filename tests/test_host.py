@@ -33,9 +33,9 @@ def test_struct_layouts_match_header(built_lib):
     assert ctypes.sizeof(_lib.Mismatch) == 8 + 4096
     assert ctypes.sizeof(_lib.Record) == 32
     assert ctypes.sizeof(_lib.EngineInfo) == 72 and _lib.EngineInfo.pinned_bytes.offset == 56  # ABI 3 callers pass 56
-    assert ctypes.sizeof(_lib.PlanModel) == 104 and _lib.PlanModel.gpu_seconds.offset == 56  # ABI 4 ...
+    assert ctypes.sizeof(_lib.PlanModel) == 112 and _lib.PlanModel.gpu_seconds.offset == 56  # ABI 4 ...
     assert _lib.PlanModel.fill_rate.offset == 96                                             # ... whose callers pass 96
-    assert ctypes.sizeof(_lib.PlanCalib) == 56
+    assert ctypes.sizeof(_lib.PlanCalib) == 64
 
 
 def test_no_gpu_means_loud_failure(built_lib):

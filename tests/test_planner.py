@@ -322,6 +322,49 @@ def test_fill_rate_calibration_and_what_it_changes(built_lib):
     assert _observe(c, 3, 0, 0) == 1 and abs(_apply(c, 0)[1] - (0.75 * 6e9 + 0.25 * 9e9)) < 1e6
 
 
+def test_what_a_call_of_small_files_may_say_about_the_box(built_lib):
+    """Round 5, found on the GPU box (profiles/r05_small_files.txt): after a tree of 5 000 x 8 KiB the ctx's link estimate was
+    41 GB/s (three copies of 12 MiB measure their latency) and its fill rate at the floor (the threads had spent their time in
+    open(), not in bytes) -- and the next big tree was planned with both.  A call is now sorted by what it can speak about:
+    the link from copies of 32 MiB and more, the fill rate from streams of 256 KiB and more (net of the per-file cost), and a
+    call of small files speaks about what a FILE costs a fill thread, which is calibrated too (both ways, 0.3 .. 2 x 10 us)."""
+    import ctypes
+    from snappy_amd import _lib
+    L = _lib.lib()
+
+    def call(c, files, nbytes, streams, copies, h2d_s, fill_s):
+        assert L.snaphash_calib_observe_call(ctypes.byref(c), files, float(nbytes), float(streams), float(copies), float(h2d_s), float(fill_s)) == 0
+
+    c = _calib()
+    # 5 000 x 8 KiB: 41 MB in six copies at 30 GB/s (latency), 37 ms of fill threads: neither the link nor the fill RATE hears of it
+    call(c, 1, 5000 * 8192, 5000, 6, 5000 * 8192 / 30e9, 0.037)
+    assert c.n_dma == 0 and c.n_fill_files == 0 and c.dma == 0 and c.fill_files == 0
+    # ... the per-file cost does: (37 ms - 41 MB / 6.5 GB/s) / 5 000 = 6.1 us
+    assert c.n_fill_per_file == 1 and abs(c.fill_per_file - (0.037 - 5000 * 8192 / 6.5e9) / 5000) < 1e-9
+    pm = _lib.PlanModel(ctypes.sizeof(_lib.PlanModel))
+    pm.from_files = 1
+    assert L.snaphash_calib_apply(ctypes.byref(c), ctypes.byref(pm)) == 0 and abs(pm.fill_per_file - c.fill_per_file) < 1e-12
+    pm = _lib.PlanModel(ctypes.sizeof(_lib.PlanModel))
+    assert L.snaphash_calib_apply(ctypes.byref(c), ctypes.byref(pm)) == 0 and pm.fill_per_file == 0.0   # memory sources open nothing
+    # config 2 (10 001 x 1 MiB in 42 copies): all three constants, the fill rate net of the files' own cost
+    call(c, 1, 10001 * MiB, 10001, 42, 10001 * MiB / 50e9, 10001 * MiB / 5e9 + 10001 * c.fill_per_file)
+    assert c.n_dma == 1 and abs(c.dma - 50e9) < 1e6 and c.n_fill_files == 1 and abs(c.fill_files - 5e9) < 1e7 and c.n_fill_per_file == 1
+    # a few dozen files say nothing about a file's cost; 64 KiB .. 256 KiB on average speaks about neither
+    before = (c.fill_per_file, c.fill_files)
+    call(c, 1, 100 * 4096, 100, 1, 1e-4, 0.01)
+    call(c, 1, 5000 * (128 << 10), 5000, 30, 0.02, 0.5)
+    assert (c.fill_per_file, c.fill_files) == before and c.n_dma == 1
+    # an absurd one (a cold cache: 1 ms a file) is cut where it enters, and moves the estimate a quarter of the way
+    call(c, 1, 5000 * 8192, 5000, 6, 1e-3, 5.0)
+    assert abs(c.fill_per_file - (0.75 * before[0] + 0.25 * 20e-6)) < 1e-9
+    assert _observe(c, 6, 10, 1.0) == 0 and _observe(c, 6, 5000, 5000 * 1e-9) == 0   # too few files; no box opens a file in a nanosecond
+    # what it changes: the GPU part of 20 000 small files is modelled by its opens
+    lens = [8192] * 20000
+    _, slow = _plan(lens, from_files=1, host_threads=1, cpus=2, fill_threads=12)
+    _, fast = _plan(lens, from_files=1, host_threads=1, cpus=2, fill_threads=12, fill_per_file=5e-6)
+    assert fast["gpu_seconds"] < 0.7 * slow["gpu_seconds"]
+
+
 def test_abi4_sized_structs_are_still_taken(built_lib):
     """A caller built against ABI 4 passes the shorter snaphash_plan_model (no fill_rate)."""
     import ctypes

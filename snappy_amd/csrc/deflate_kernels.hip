@@ -111,7 +111,15 @@ struct HuffScratch {
     DynHeader hdr;
 };
 
+constexpr uint32_t kMirror = 48; // the ring's first bytes again behind its end: a run of reads that starts inside the ring never wraps (below)
+
 struct ChunkLds {
+    // FIRST, at LDS address 0 (round 5): a read of the stream is then `pos & mask` and nothing else -- behind the ring and the
+    // heads it was a mask AND an add of 0x14000 per read, which no ds_read's 16-bit offset field holds; the links' ring now
+    // sits at 32 816, which the field does hold
+    uint8_t data[kDataRing + kMirror]; // 32 KB: the stream around the segment in work, a ring by position; its first 48
+                                       // bytes are mirrored behind its end so that an unaligned read -- or the four 8-byte
+                                       // reads of one extension step, 32 bytes from one masked address -- never wraps
     // the block image (emission) overlays the ring and the heads: both are spent when the codes are built
     union {
         struct {
@@ -120,8 +128,6 @@ struct ChunkLds {
         } ix;
         uint32_t image[(kDfChunk + 16384u) / 4u]; // 80 KB: a block that shrinks is < 64 KiB + framing
     };
-    uint8_t data[kDataRing + 16];     // 32 KB: the stream around the segment in work, a ring by position; its first 16
-                                      // bytes are mirrored behind its end so that an unaligned read never wraps
     // search results of three segments in flight (searched | being parsed | being finished); afterwards the scratch of
     // the code construction and the tile offsets
     union {
@@ -182,7 +188,7 @@ __device__ __forceinline__ void stage_bytes(ChunkLds& L, const uint8_t* __restri
     }
     const uint32_t at = (uint32_t)p & kDataMask;
     *reinterpret_cast<uint4*>(L.data + at) = v;
-    if (at == 0u) *reinterpret_cast<uint4*>(L.data + kDataRing) = v; // the mirror behind the ring's end
+    if (at < kMirror) *reinterpret_cast<uint4*>(L.data + kDataRing + at) = v; // the mirror behind the ring's end
 }
 
 // ---- indexing one segment [seg0, seg0 + kDfSeg) ----------------------------------------------------------------
@@ -268,8 +274,13 @@ __device__ __forceinline__ uint32_t extend_match(const ChunkLds& L, uint32_t p, 
     if (x0) { const uint32_t l = (uint32_t)__builtin_ctzll(x0) >> 3; return l < maxl ? l : maxl; }
     uint32_t l = 8u;
     while (l < maxl) {
-        const uint64_t a0 = d64(L, p + l) ^ d64(L, cand + l), a1 = d64(L, p + l + 8u) ^ d64(L, cand + l + 8u),
-                       a2 = d64(L, p + l + 16u) ^ d64(L, cand + l + 16u), a3 = d64(L, p + l + 24u) ^ d64(L, cand + l + 24u);
+        // (one masked address a side: the mirror behind the ring's end covers the 32 bytes from any address inside it)
+        const uint8_t* pa = L.data + ((p + l) & kDataMask);
+        const uint8_t* ca = L.data + ((cand + l) & kDataMask);
+        const uint64_t a0 = *reinterpret_cast<const u64_unaligned*>(pa) ^ *reinterpret_cast<const u64_unaligned*>(ca),
+                       a1 = *reinterpret_cast<const u64_unaligned*>(pa + 8) ^ *reinterpret_cast<const u64_unaligned*>(ca + 8),
+                       a2 = *reinterpret_cast<const u64_unaligned*>(pa + 16) ^ *reinterpret_cast<const u64_unaligned*>(ca + 16),
+                       a3 = *reinterpret_cast<const u64_unaligned*>(pa + 24) ^ *reinterpret_cast<const u64_unaligned*>(ca + 24);
         if ((a0 | a1) | (a2 | a3)) {
             if (a0) l += (uint32_t)__builtin_ctzll(a0) >> 3;
             else if (a1) l += 8u + ((uint32_t)__builtin_ctzll(a1) >> 3);
@@ -379,36 +390,39 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
 #elif !defined(SNAPHASH_DF_BRANCHY_WALK) // the shipped walk: check, extend, update written out per candidate
     // (The inner decisions are selects, not branches: every `if` of a divergent wave costs scalar instructions for the
     // exec mask -- the kernel issued as many of those as vector instructions -- and only the ones that skip real work
-    // (a link not wanted, a candidate that fails its check word, the extension) are worth them.)
-#if defined(SNAPHASH_DF_GUARDED_LINKS)
-#define SNAPHASH_DF_LINK_GUARD if (more && ncand < left)
-#else
-#define SNAPHASH_DF_LINK_GUARD
-#endif
+    // (a candidate that fails its check word, the extension) are worth them.)
+    // (Round 5: the links' bookkeeping in lane masks.  A link is a candidate when the one before it was, the budget wants
+    // it (link k of a batch: k < left) and it leads to a position inside the window -- `ok` of link k implies `ok` of link
+    // k - 1, so "candidate k exists" is ok_k itself and the chain goes on iff the LAST wanted link was there.  The earlier
+    // form carried `more` and a candidate count through every link as vector registers -- a 0/1 select, its conversion
+    // back into a mask, an add and a compare a link: sixteen vector instructions a link where this takes ten.)
     while (more && left) {
-        uint32_t c0_ = 0, c1_ = 0, c2_ = 0, c3_ = 0, ncand = 0;
-#define SNAPHASH_DF_LINK(dst)                                                       \
-        SNAPHASH_DF_LINK_GUARD {                                                    \
-            const bool want_ = more && ncand < left;                                \
+        const uint32_t lim = left; // links this batch may take (the first `lim` of its four)
+        uint32_t c0_, c1_, c2_, c3_;
+        bool ok0, ok1, ok2, ok3;
+#define SNAPHASH_DF_LINK(k, dst, okv, prev)                                         \
+        {                                                                           \
             const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
-            const bool ok_ = want_ && d_ != 0u && p - (cur - d_) <= kDfMaxDist;     \
-            more = want_ ? ok_ : more;                                              \
-            cur = ok_ ? cur - d_ : cur;                                             \
-            dst = ok_ ? cur : 0u;                                                   \
-            ncand += ok_ ? 1u : 0u;                                                 \
+            const uint32_t nxt_ = cur - d_;                                         \
+            okv = (prev) && (k) < lim && d_ != 0u && p - nxt_ <= kDfMaxDist;        \
+            cur = okv ? nxt_ : cur;                                                 \
+            dst = okv ? nxt_ : 0u;                                                  \
         }
-        SNAPHASH_DF_LINK(c0_) SNAPHASH_DF_LINK(c1_) SNAPHASH_DF_LINK(c2_) SNAPHASH_DF_LINK(c3_)
+        SNAPHASH_DF_LINK(0u, c0_, ok0, true) SNAPHASH_DF_LINK(1u, c1_, ok1, ok0) SNAPHASH_DF_LINK(2u, c2_, ok2, ok1) SNAPHASH_DF_LINK(3u, c3_, ok3, ok2)
 #undef SNAPHASH_DF_LINK
+        more = ok3 || (lim == 3u && ok2) || (lim == 2u && ok1) || (lim == 1u && ok0); // (ok3 implies lim >= 4)
         const uint32_t off = best >= 3u ? best - 3u : 0u;
         const uint32_t mine = d32(L, p + off);
         // the candidates' check words come through L1/L2 (the texture path), not from the data ring: the ring's LDS
         // pipe is what bounds the walk (links, this position's words, the extensions), and the two paths run side by
         // side (12.6 instead of 14.5 ms per 64 MiB of text)
-        const uint8_t* gb = in + (p64 - p);
-        const uint32_t k0 = *reinterpret_cast<const u32_unaligned*>(gb + c0_ + off), k1 = *reinterpret_cast<const u32_unaligned*>(gb + c1_ + off),
-                       k2 = *reinterpret_cast<const u32_unaligned*>(gb + c2_ + off), k3 = *reinterpret_cast<const u32_unaligned*>(gb + c3_ + off);
-#define SNAPHASH_DF_EVAL(k, cand, chk)                                                                         \
-        if (k < ncand && left) {                                                                                \
+        // (round 5: a scalar base and ONE 32-bit offset a load -- the tile's positions share the upper half of their 64-bit
+        // position, a tile never straddles 4 GiB -- where `gb + c + off` was two 64-bit vector additions a candidate)
+        const uint8_t* gb = in + ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((p64 - p) >> 32)) << 32);
+        const uint32_t k0 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(c0_ + off)), k1 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(c1_ + off)),
+                       k2 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(c2_ + off)), k3 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(c3_ + off));
+#define SNAPHASH_DF_EVAL(okv, cand, chk)                                                                        \
+        if (okv && left) {                                                                                      \
             --left;                                                                                             \
             bool go = true;                                                                                     \
             if (best >= 3u) go = (off == best - 3u) ? (chk == mine) : (d32(L, cand + best - 3u) == d32(L, p + best - 3u)); \
@@ -421,7 +435,7 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
                 best = better ? l : best;                                                                       \
             }                                                                                                   \
         }
-        SNAPHASH_DF_EVAL(0u, c0_, k0) SNAPHASH_DF_EVAL(1u, c1_, k1) SNAPHASH_DF_EVAL(2u, c2_, k2) SNAPHASH_DF_EVAL(3u, c3_, k3)
+        SNAPHASH_DF_EVAL(ok0, c0_, k0) SNAPHASH_DF_EVAL(ok1, c1_, k1) SNAPHASH_DF_EVAL(ok2, c2_, k2) SNAPHASH_DF_EVAL(ok3, c3_, k3)
 #undef SNAPHASH_DF_EVAL
     }
 #else // round 3's branches (make branchy, for A/B)
@@ -1042,7 +1056,7 @@ __global__ __launch_bounds__(1024) void deflate_chunks_kernel(const uint8_t* __r
         else for (uint32_t k = 0; k < 16u; ++k) if (p + k < n_in) reinterpret_cast<uint8_t*>(&v)[k] = in[p + k];
         const uint32_t at = (uint32_t)p & kDataMask;
         *reinterpret_cast<uint4*>(L.data + at) = v;
-        if (at == 0u) *reinterpret_cast<uint4*>(L.data + kDataRing) = v;
+        if (at < kMirror) *reinterpret_cast<uint4*>(L.data + kDataRing + at) = v;
     }
     for (uint32_t i = threadIdx.x; i < kChunkTiles; i += kThreads) { // the parse ORs / adds a tile's starts, matches and match count together
         L.startbits[i] = 0ull;

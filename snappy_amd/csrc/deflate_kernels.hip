@@ -396,8 +396,13 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     // k - 1, so "candidate k exists" is ok_k itself and the chain goes on iff the LAST wanted link was there.  The earlier
     // form carried `more` and a candidate count through every link as vector registers -- a 0/1 select, its conversion
     // back into a mask, an add and a compare a link: sixteen vector instructions a link where this takes ten.)
+#if defined(SNAPHASH_DF_FRESH_CHECKS)
+    const bool first_alone = false;
+#else
+    bool first_alone = true; // the first batch is ONE link: it finds a best to check the others against (below)
+#endif
     while (more && left) {
-        const uint32_t lim = left; // links this batch may take (the first `lim` of its four)
+        const uint32_t lim = first_alone ? 1u : left; // links this batch may take (the first `lim` of its four)
         uint32_t c0_, c1_, c2_, c3_;
         bool ok0, ok1, ok2, ok3;
 #define SNAPHASH_DF_LINK(k, dst, okv, prev)                                         \
@@ -421,11 +426,21 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
         const uint8_t* gb = in + ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((p64 - p) >> 32)) << 32);
         const uint32_t k0 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(c0_ + off)), k1 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(c1_ + off)),
                        k2 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(c2_ + off)), k3 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(c3_ + off));
+        // Round 5: every candidate of a batch is checked against the best the batch STARTED with -- a check only ever spares
+        // work, so an older best means at most an extension that did not have to be -- where a candidate behind one that
+        // raised the best used to fetch two fresh check words from LDS, under three nested branches.  The batch that would
+        // pay for that is the first (no best yet: all four extended), so the first batch is one link.
+#if defined(SNAPHASH_DF_FRESH_CHECKS)
+#define SNAPHASH_DF_GO(cand, chk) (best < 3u || ((off == best - 3u) ? (chk == mine) : (d32(L, cand + best - 3u) == d32(L, p + best - 3u))))
+#else
+        const bool nochk = best < 3u;
+        first_alone = false;
+#define SNAPHASH_DF_GO(cand, chk) (nochk || chk == mine)
+#endif
 #define SNAPHASH_DF_EVAL(okv, cand, chk)                                                                        \
         if (okv && left) {                                                                                      \
             --left;                                                                                             \
-            bool go = true;                                                                                     \
-            if (best >= 3u) go = (off == best - 3u) ? (chk == mine) : (d32(L, cand + best - 3u) == d32(L, p + best - 3u)); \
+            const bool go = SNAPHASH_DF_GO(cand, chk);                                                          \
             if (go) {                                                                                           \
                 const uint32_t l = extend_match(L, p, cand, maxl);                                              \
                 const bool better = l > best;                                                                   \
@@ -437,6 +452,7 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
         }
         SNAPHASH_DF_EVAL(ok0, c0_, k0) SNAPHASH_DF_EVAL(ok1, c1_, k1) SNAPHASH_DF_EVAL(ok2, c2_, k2) SNAPHASH_DF_EVAL(ok3, c3_, k3)
 #undef SNAPHASH_DF_EVAL
+#undef SNAPHASH_DF_GO
     }
 #else // round 3's branches (make branchy, for A/B)
     while (more && left) {

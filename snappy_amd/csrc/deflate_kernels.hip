@@ -123,7 +123,7 @@ struct ChunkLds {
     // the block image (emission) overlays the ring and the heads: both are spent when the codes are built
     union {
         struct {
-            uint16_t ring[kDfRing];   // 64 KB: distance to the previous position with the same hash, 0 = none
+            uint16_t ring[kDfRing];   // 64 KB: distance to the previous position with the same hash, kNoLink = none
             uint32_t head[kHeadN];    // 16 KB: newest indexed position + 1 - s0, 0 = none
         } ix;
         uint32_t image[(kDfChunk + 16384u) / 4u]; // 80 KB: a block that shrinks is < 64 KiB + framing
@@ -201,6 +201,11 @@ __device__ __forceinline__ void stage_bytes(ChunkLds& L, const uint8_t* __restri
 //   B, wave 0, tile after tile: the links ACROSS tiles.  A kNeedsHead lane takes its link from head[h]; a last lane
 //      becomes head[h].  The head read of a tile is in flight while the next tile's hashes are computed.
 constexpr uint32_t kNeedsHead = 0xFFFFu; // (a genuine link is at most 65 534: longer ones are cut, as in the model)
+// "No older position": a distance beyond any window (round 5; it was 0).  A walk ends at a link that leaves the window,
+// so the end of a chain needs no test of its own -- one compare a link instead of two.  (A genuine link of 65 534 and more
+// is stored as this: it was beyond the window anyway.)
+constexpr uint32_t kNoLink = 0xFFFEu;
+static_assert(kNoLink > kDfMaxDist, "the end of a chain fails the window test");
 
 __device__ __forceinline__ void index_tile_inside(ChunkLds& L, uint8_t* __restrict__ owner, uint64_t n_in, uint64_t seg0, uint32_t t, uint64_t c1,
                                                   uint32_t lane)
@@ -249,8 +254,8 @@ __device__ __forceinline__ void index_segment_across(ChunkLds& L, uint64_t n_in,
             last = (L.lastmask[t] >> lane) & 1ull;
         }
         if (p_need) { // the previous tile: its head values have arrived
-            uint32_t d = p_q1 ? p_rel1 - p_q1 : 0u;
-            if (d >= kNeedsHead) d = 0u;
+            uint32_t d = p_q1 ? p_rel1 - p_q1 : kNoLink;
+            if (d > kNoLink) d = kNoLink;
             L.ix.ring[p_pos & kRingMask] = (uint16_t)d;
         }
         if (p_last) L.ix.head[p_h] = p_rel1;
@@ -409,12 +414,17 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
         {                                                                           \
             const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
             const uint32_t nxt_ = cur - d_;                                         \
-            okv = (prev) && (k) < lim && d_ != 0u && p - nxt_ <= kDfMaxDist;        \
-            cur = okv ? nxt_ : cur;                                                 \
-            dst = okv ? nxt_ : 0u;                                                  \
+            okv = (prev) && (k) < lim && p - nxt_ <= kDfMaxDist; /* (kNoLink fails it) */ \
+            cur = nxt_; /* (behind a link that was not taken nothing of this lane's walk is used again: the chain has ended, or the \
+                           budget has -- lim = left, and every candidate visited costs one -- and the ring's index is masked; the \
+                           one-link first batch puts its `cur` back below) */ \
+            dst = okv ? nxt_ : 0u; /* (the check word is loaded whatever ok says: a safe address) */ \
         }
-        SNAPHASH_DF_LINK(0u, c0_, ok0, true) SNAPHASH_DF_LINK(1u, c1_, ok1, ok0) SNAPHASH_DF_LINK(2u, c2_, ok2, ok1) SNAPHASH_DF_LINK(3u, c3_, ok3, ok2)
+        SNAPHASH_DF_LINK(0u, c0_, ok0, true)
+        const uint32_t cur_after0 = cur;
+        SNAPHASH_DF_LINK(1u, c1_, ok1, ok0) SNAPHASH_DF_LINK(2u, c2_, ok2, ok1) SNAPHASH_DF_LINK(3u, c3_, ok3, ok2)
 #undef SNAPHASH_DF_LINK
+        cur = first_alone ? cur_after0 : cur;
         more = ok3 || (lim == 3u && ok2) || (lim == 2u && ok1) || (lim == 1u && ok0); // (ok3 implies lim >= 4)
         const uint32_t off = best >= 3u ? best - 3u : 0u;
         const uint32_t mine = d32(L, p + off);
@@ -443,11 +453,11 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
             const bool go = SNAPHASH_DF_GO(cand, chk);                                                          \
             if (go) {                                                                                           \
                 const uint32_t l = extend_match(L, p, cand, maxl);                                              \
-                const bool better = l > best;                                                                   \
-                const uint32_t cut = (l >= kDfNice || l >= maxl) ? 0u : ((l >= kDfGood && left > depth / 4u) ? depth / 4u : left); \
-                bdist = better ? p - cand : bdist;                                                              \
-                left = better ? cut : left;                                                                     \
-                best = better ? l : best;                                                                       \
+                if (l > best) { /* (a branch: most extensions end short of the best, and the update is a dozen instructions) */ \
+                    best = l;                                                                                   \
+                    bdist = p - cand;                                                                           \
+                    left = (l >= kDfNice || l >= maxl) ? 0u : ((l >= kDfGood && left > depth / 4u) ? depth / 4u : left); \
+                }                                                                                               \
             }                                                                                                   \
         }
         SNAPHASH_DF_EVAL(ok0, c0_, k0) SNAPHASH_DF_EVAL(ok1, c1_, k1) SNAPHASH_DF_EVAL(ok2, c2_, k2) SNAPHASH_DF_EVAL(ok3, c3_, k3)

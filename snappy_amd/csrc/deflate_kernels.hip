@@ -392,7 +392,76 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
             }
         }
     }
-#elif !defined(SNAPHASH_DF_BRANCHY_WALK) // the shipped walk: check, extend, update written out per candidate
+#elif !defined(SNAPHASH_DF_BRANCHY_WALK) && !defined(SNAPHASH_DF_UNPIPELINED) // the shipped walk
+    // Round 5, the walk as a two-stage pipeline.  A batch is four links -- four DEPENDENT reads of the ring -- then four
+    // check words from L2, then the survivors' extensions; with four waves on a SIMD little else hides either latency, and
+    // once the bookkeeping was down to ~85 vector instructions a batch the kernel waited for them.  The links of the NEXT
+    // batch do not need the candidates of this one (only the budget does, and a link walked in vain costs nothing but
+    // itself), so they are walked while this batch's check words are on their way:
+    //     links(0) | loads(0) links(1) evaluate(0) | loads(1) links(2) evaluate(1) | ...
+    // What a batch's links leave behind: the candidates a0..a3 and, as lane masks, whether each exists -- the chain reached
+    // it inside the window (kNoLink fails that test; `exists` of link k implies `exists` of link k - 1).  Candidate k is
+    // visited when it exists and the budget reaches it (k < left at the batch's start); the chain goes on behind a batch
+    // iff its last link exists.  The first batch is ONE link: it finds a best to check the others against -- every
+    // candidate of a batch is checked against the best the batch STARTED with (a check only ever spares work, so an older
+    // best means at most an extension that did not have to be).  Exactly the serial walk's result.
+    uint32_t a0, a1 = 0u, a2 = 0u, a3 = 0u;
+    bool e0, e1 = false, e2 = false, e3 = false;
+    bool last_exists; // ... of the batch in work: the chain goes on behind it
+    {
+        const uint32_t d_ = L.ix.ring[cur & kRingMask];
+        cur -= d_;
+        e0 = p - cur <= kDfMaxDist;
+        a0 = e0 ? cur : 0u;
+        last_exists = e0;
+    }
+    // (the check word is loaded whatever `exists` says: a safe address, 0, where it does not)
+    const uint8_t* gb = in + ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((p64 - p) >> 32)) << 32);
+    bool open = e0;
+    (void)more;
+    while (open) {
+        const bool nochk = best < 3u;
+        const uint32_t off = nochk ? 0u : best - 3u;
+        const uint32_t mine = d32(L, p + off);
+        // the candidates' check words come through L1/L2 (the texture path), not from the data ring: the ring's LDS pipe is
+        // what bounds the walk (links, this position's words, the extensions), and the two paths run side by side; a scalar
+        // base and ONE 32-bit offset a load (the tile's positions share the upper half of their 64-bit position)
+        const uint32_t k0 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(a0 + off)), k1 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(a1 + off)),
+                       k2 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(a2 + off)), k3 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(a3 + off));
+        // the next batch's links, while those are in flight
+        uint32_t n0, n1, n2, n3;
+        bool f0, f1, f2, f3;
+#define SNAPHASH_DF_LINK(dst, ex, prev)                                             \
+        {                                                                           \
+            const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
+            cur -= d_; /* (behind a link that does not exist nothing of this lane's walk is used again; the ring's index is masked) */ \
+            ex = (prev) && p - cur <= kDfMaxDist;                                   \
+            dst = ex ? cur : 0u;                                                    \
+        }
+        SNAPHASH_DF_LINK(n0, f0, last_exists) SNAPHASH_DF_LINK(n1, f1, f0) SNAPHASH_DF_LINK(n2, f2, f1) SNAPHASH_DF_LINK(n3, f3, f2)
+#undef SNAPHASH_DF_LINK
+        /* (a candidate is visited while budget is left: every visit costs one, a match may cut the rest) */
+#define SNAPHASH_DF_EVAL(k, ex, cand, chk)                                                                      \
+        if (ex && left) {                                                                                       \
+            --left;                                                                                             \
+            if (nochk || chk == mine) {                                                                         \
+                const uint32_t l = extend_match(L, p, cand, maxl);                                              \
+                if (l > best) { /* (a branch: most extensions end short of the best, and the update is a dozen instructions) */ \
+                    best = l;                                                                                   \
+                    bdist = p - cand;                                                                           \
+                    left = (l >= kDfNice || l >= maxl) ? 0u : ((l >= kDfGood && left > depth / 4u) ? depth / 4u : left); \
+                }                                                                                               \
+            }                                                                                                   \
+        }
+        SNAPHASH_DF_EVAL(0u, e0, a0, k0) SNAPHASH_DF_EVAL(1u, e1, a1, k1) SNAPHASH_DF_EVAL(2u, e2, a2, k2) SNAPHASH_DF_EVAL(3u, e3, a3, k3)
+#undef SNAPHASH_DF_EVAL
+        // on iff the chain goes on behind this batch (its last link exists) and budget is left
+        open = last_exists && left != 0u;
+        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        e0 = f0; e1 = f1; e2 = f2; e3 = f3;
+        last_exists = f3;
+    }
+#elif !defined(SNAPHASH_DF_BRANCHY_WALK) // round 5's walk before the pipeline (make unpipelined, for A/B): check, extend, update written out per candidate
     // (The inner decisions are selects, not branches: every `if` of a divergent wave costs scalar instructions for the
     // exec mask -- the kernel issued as many of those as vector instructions -- and only the ones that skip real work
     // (a candidate that fails its check word, the extension) are worth them.)

@@ -408,10 +408,15 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     uint32_t a0, a1 = 0u, a2 = 0u, a3 = 0u;
     bool e0, e1 = false, e2 = false, e3 = false;
     bool last_exists; // ... of the batch in work: the chain goes on behind it
+    // The window test of a link is the BORROW of a subtraction: `room` is how far the chain may still go back (kDfMaxDist less
+    // the distance walked), a link's distance comes off it, and a link that leaves the window -- or kNoLink -- borrows
+    // (v_sub_co_u32: one instruction where "distance from p, compare with the window" was two).  Behind a borrow `room` is
+    // garbage, and so is `cur`: nothing of the lane's walk is used again (`exists` of link k implies `exists` of link k - 1).
+    uint32_t room = kDfMaxDist;
     {
         const uint32_t d_ = L.ix.ring[cur & kRingMask];
         cur -= d_;
-        e0 = p - cur <= kDfMaxDist;
+        e0 = !__builtin_sub_overflow(room, d_, &room);
         a0 = e0 ? cur : 0u;
         last_exists = e0;
     }
@@ -434,8 +439,8 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
 #define SNAPHASH_DF_LINK(dst, ex, prev)                                             \
         {                                                                           \
             const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
-            cur -= d_; /* (behind a link that does not exist nothing of this lane's walk is used again; the ring's index is masked) */ \
-            ex = (prev) && p - cur <= kDfMaxDist;                                   \
+            cur -= d_; /* (the ring's index is masked: any value reads) */          \
+            ex = !__builtin_sub_overflow(room, d_, &room) && (prev);                \
             dst = ex ? cur : 0u;                                                    \
         }
         SNAPHASH_DF_LINK(n0, f0, last_exists) SNAPHASH_DF_LINK(n1, f1, f0) SNAPHASH_DF_LINK(n2, f2, f1) SNAPHASH_DF_LINK(n3, f3, f2)

@@ -273,11 +273,22 @@ __device__ __forceinline__ void index_segment_across(ChunkLds& L, uint64_t n_in,
 // instruction every ~6 cycles with four waves per SIMD: it waits).  Reads run up to 31 bytes past the match's end: inside
 // the data ring (the look-ahead covers 258 + 8; what lies beyond only ever raises a length that is cut to maxl).
 #if !defined(SNAPHASH_DF_NARROW_EXTEND)
+// index of the lowest set bit, 0xFFFFFFFF for 0 (v_ffbl_b32 as the hardware has it: __builtin_ctz of 0 is undefined)
+__device__ __forceinline__ uint32_t ffbl_or_ones(uint32_t x)
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ uint32_t extend_match(const ChunkLds& L, uint32_t p, uint32_t cand, uint32_t maxl)
 {
+    // the first eight bytes without a branch (round 5): equal bytes = lowest differing bit / 8; of the upper word `| 32` adds
+    // the lower word's 32 bits and leaves "no bit set" what it is, so that eight equal bytes come out as a huge count
     const uint64_t x0 = d64(L, p) ^ d64(L, cand);
-    if (x0) { const uint32_t l = (uint32_t)__builtin_ctzll(x0) >> 3; return l < maxl ? l : maxl; }
-    uint32_t l = 8u;
+    const uint32_t lo_ = ffbl_or_ones((uint32_t)x0), hi_ = ffbl_or_ones((uint32_t)(x0 >> 32)) | 32u;
+    uint32_t l = (lo_ < hi_ ? lo_ : hi_) >> 3;
+    if (l < 8u) return l < maxl ? l : maxl;
+    l = 8u;
     while (l < maxl) {
         // (one masked address a side: the mirror behind the ring's end covers the 32 bytes from any address inside it)
         const uint8_t* pa = L.data + ((p + l) & kDataMask);
@@ -440,16 +451,20 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
         {                                                                           \
             const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
             cur -= d_; /* (the ring's index is masked: any value reads) */          \
-            ex = !__builtin_sub_overflow(room, d_, &room) && (prev);                \
+            const bool out_ = __builtin_sub_overflow(room, d_, &room);              \
+            ex = (prev) & !out_;                                                    \
             dst = ex ? cur : 0u;                                                    \
         }
         SNAPHASH_DF_LINK(n0, f0, last_exists) SNAPHASH_DF_LINK(n1, f1, f0) SNAPHASH_DF_LINK(n2, f2, f1) SNAPHASH_DF_LINK(n3, f3, f2)
 #undef SNAPHASH_DF_LINK
         /* (a candidate is visited while budget is left: every visit costs one, a match may cut the rest) */
+        /* (a wave issues ONE instruction of any kind every four cycles and this kernel is bound by exactly that count -- scalar   \
+           exec-mask bookkeeping included, 40 % of it: the visit's accounting is a select outside the one branch a candidate costs) */ \
 #define SNAPHASH_DF_EVAL(k, ex, cand, chk)                                                                      \
-        if (ex && left) {                                                                                       \
-            --left;                                                                                             \
-            if (nochk || chk == mine) {                                                                         \
+        {                                                                                                       \
+            const bool vis_ = (ex) & (left != 0u);                                                              \
+            left -= vis_ ? 1u : 0u;                                                                             \
+            if (vis_ & (nochk | (chk == mine))) {                                                               \
                 const uint32_t l = extend_match(L, p, cand, maxl);                                              \
                 if (l > best) { /* (a branch: most extensions end short of the best, and the update is a dozen instructions) */ \
                     best = l;                                                                                   \

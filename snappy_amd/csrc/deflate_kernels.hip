@@ -405,82 +405,96 @@ __device__ __forceinline__ uint32_t search_position(const ChunkLds& L, const uin
     }
 #elif !defined(SNAPHASH_DF_BRANCHY_WALK) && !defined(SNAPHASH_DF_UNPIPELINED) // the shipped walk
     // Round 5, the walk as a two-stage pipeline.  A batch is four links -- four DEPENDENT reads of the ring -- then four
-    // check words from L2, then the survivors' extensions; with four waves on a SIMD little else hides either latency, and
-    // once the bookkeeping was down to ~85 vector instructions a batch the kernel waited for them.  The links of the NEXT
-    // batch do not need the candidates of this one (only the budget does, and a link walked in vain costs nothing but
-    // itself), so they are walked while this batch's check words are on their way:
-    //     links(0) | loads(0) links(1) evaluate(0) | loads(1) links(2) evaluate(1) | ...
-    // What a batch's links leave behind: the candidates a0..a3 and, as lane masks, whether each exists -- the chain reached
-    // it inside the window (kNoLink fails that test; `exists` of link k implies `exists` of link k - 1).  Candidate k is
-    // visited when it exists and the budget reaches it (k < left at the batch's start); the chain goes on behind a batch
-    // iff its last link exists.  The first batch is ONE link: it finds a best to check the others against -- every
-    // candidate of a batch is checked against the best the batch STARTED with (a check only ever spares work, so an older
-    // best means at most an extension that did not have to be).  Exactly the serial walk's result.
-    uint32_t a0, a1 = 0u, a2 = 0u, a3 = 0u;
-    bool e0, e1 = false, e2 = false, e3 = false;
-    bool last_exists; // ... of the batch in work: the chain goes on behind it
-    // The window test of a link is the BORROW of a subtraction: `room` is how far the chain may still go back (kDfMaxDist less
-    // the distance walked), a link's distance comes off it, and a link that leaves the window -- or kNoLink -- borrows
-    // (v_sub_co_u32: one instruction where "distance from p, compare with the window" was two).  Behind a borrow `room` is
-    // garbage, and so is `cur`: nothing of the lane's walk is used again (`exists` of link k implies `exists` of link k - 1).
+    // check words from L2, then the survivors' extensions.  The links of the NEXT batch do not need the candidates of this
+    // one (only the budget does, and a link walked in vain costs nothing but itself), so they are walked while this
+    // batch's check words are on their way:
+    //     link 0 | links(1) extend(0) | loads(1) links(2) evaluate(1) | loads(2) links(3) evaluate(2) | ...
+    // What the kernel is bound by (profiles/r05_deflate_experiments.txt): a wave issues ONE instruction of any kind every
+    // four cycles, and the counters say its waves do exactly that -- 298 000 instructions in 1 157 000 cycles, 40 % of them
+    // scalar exec-mask bookkeeping.  So every instruction counts, the scalar ones like the vector ones:
+    //   * what a batch's links leave behind is the candidates a0..a3 and, as lane masks, whether each is DEAD -- the chain
+    //     had left the window before it (kNoLink does; `dead` of link k implies `dead` of every later one: one s_or a link).
+    //     The window test is the BORROW of a subtraction: `room` is how far the chain may still go back, a link's distance
+    //     comes off it, and a link that leaves the window borrows (behind a borrow `room` and `cur` are garbage, and
+    //     nothing of the lane's walk is used again);
+    //   * the budget is a LIMIT, not a countdown: candidate k of a batch is visited iff it is alive and k < lim (lim = the
+    //     budget at the batch's start); a match that cuts the budget at candidate k re-bases the limit -- lim = the cut
+    //     budget + k + 1 -- and the batch's end takes the visits off in one go.  (The serial walk counts a visit at a time:
+    //     same visits, same cuts.)
+    //   * the first candidate is taken out of the loop: there is no best to check it against, so it is extended without a
+    //     check word -- and finds the best the others are checked against;
+    //   * every candidate of a batch is checked against the best the batch STARTED with (a check only ever spares work, so
+    //     an older best means at most an extension that did not have to be).
+    // Exactly the serial walk's result.
+    (void)more;
     uint32_t room = kDfMaxDist;
+    bool last_dead; // ... of the batch in work: the chain ends inside it
     {
         const uint32_t d_ = L.ix.ring[cur & kRingMask];
         cur -= d_;
-        e0 = !__builtin_sub_overflow(room, d_, &room);
-        a0 = e0 ? cur : 0u;
-        last_exists = e0;
+        last_dead = __builtin_sub_overflow(room, d_, &room);
     }
-    // (the check word is loaded whatever `exists` says: a safe address, 0, where it does not)
+    const uint32_t first = cur; // (garbage where last_dead)
+    // (the check word is loaded whatever `dead` says: a safe address, 0, where it is)
     const uint8_t* gb = in + ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((p64 - p) >> 32)) << 32);
-    bool open = e0;
-    (void)more;
+    uint32_t a0, a1, a2, a3;
+    bool x0, x1, x2, x3; // dead
+#define SNAPHASH_DF_LINK(dst, dd, prev)                                             \
+    {                                                                               \
+        const uint32_t d_ = L.ix.ring[cur & kRingMask];                             \
+        cur -= d_; /* (the ring's index is masked: any value reads) */              \
+        const bool out_ = __builtin_sub_overflow(room, d_, &room);                  \
+        dd = (prev) | out_;                                                         \
+        dst = dd ? 0u : cur;                                                        \
+    }
+#define SNAPHASH_DF_UPDATE(k, cand, l)                                                                          \
+    if (l > best) { /* (a branch: most extensions end short of the best, and the update is a dozen instructions) */ \
+        best = l;                                                                                               \
+        bdist = p - cand;                                                                                       \
+        const uint32_t rest_ = lim - ((k) + 1u); /* the budget behind this visit */                             \
+        lim = ((l >= kDfNice || l >= maxl) ? 0u : ((l >= kDfGood && rest_ > depth / 4u) ? depth / 4u : rest_)) + ((k) + 1u); \
+    }
+    uint32_t lim = left; // the batch in work: candidate k is visited iff alive and k < lim
+    SNAPHASH_DF_LINK(a0, x0, last_dead) SNAPHASH_DF_LINK(a1, x1, x0) SNAPHASH_DF_LINK(a2, x2, x1) SNAPHASH_DF_LINK(a3, x3, x2)
+    if (!last_dead && lim != 0u) { // the first candidate
+        const uint32_t l = extend_match(L, p, first, maxl);
+        SNAPHASH_DF_UPDATE(0u, first, l)
+    }
+    left = (last_dead || lim == 0u) ? 0u : lim - 1u;
+    bool open = !x0 && left != 0u;
+    last_dead = x3;
     while (open) {
+        lim = left;
         const bool nochk = best < 3u;
         const uint32_t off = nochk ? 0u : best - 3u;
         const uint32_t mine = d32(L, p + off);
         // the candidates' check words come through L1/L2 (the texture path), not from the data ring: the ring's LDS pipe is
-        // what bounds the walk (links, this position's words, the extensions), and the two paths run side by side; a scalar
-        // base and ONE 32-bit offset a load (the tile's positions share the upper half of their 64-bit position)
+        // what the links and the extensions use, and the two paths run side by side; a scalar base and ONE 32-bit offset a
+        // load (the tile's positions share the upper half of their 64-bit position)
         const uint32_t k0 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(a0 + off)), k1 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(a1 + off)),
                        k2 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(a2 + off)), k3 = *reinterpret_cast<const u32_unaligned*>(gb + (uint32_t)(a3 + off));
         // the next batch's links, while those are in flight
         uint32_t n0, n1, n2, n3;
-        bool f0, f1, f2, f3;
-#define SNAPHASH_DF_LINK(dst, ex, prev)                                             \
-        {                                                                           \
-            const uint32_t d_ = L.ix.ring[cur & kRingMask];                         \
-            cur -= d_; /* (the ring's index is masked: any value reads) */          \
-            const bool out_ = __builtin_sub_overflow(room, d_, &room);              \
-            ex = (prev) & !out_;                                                    \
-            dst = ex ? cur : 0u;                                                    \
+        bool y0, y1, y2, y3;
+        SNAPHASH_DF_LINK(n0, y0, last_dead) SNAPHASH_DF_LINK(n1, y1, y0) SNAPHASH_DF_LINK(n2, y2, y1) SNAPHASH_DF_LINK(n3, y3, y2)
+        bool v0, v1, v2, v3; // visited
+#define SNAPHASH_DF_EVAL(k, dd, vis, cand, chk)                                                                 \
+        vis = !(dd) & ((k) < lim);                                                                              \
+        if (vis & (nochk | (chk == mine))) {                                                                    \
+            const uint32_t l = extend_match(L, p, cand, maxl);                                                  \
+            SNAPHASH_DF_UPDATE(k, cand, l)                                                                      \
         }
-        SNAPHASH_DF_LINK(n0, f0, last_exists) SNAPHASH_DF_LINK(n1, f1, f0) SNAPHASH_DF_LINK(n2, f2, f1) SNAPHASH_DF_LINK(n3, f3, f2)
-#undef SNAPHASH_DF_LINK
-        /* (a candidate is visited while budget is left: every visit costs one, a match may cut the rest) */
-        /* (a wave issues ONE instruction of any kind every four cycles and this kernel is bound by exactly that count -- scalar   \
-           exec-mask bookkeeping included, 40 % of it: the visit's accounting is a select outside the one branch a candidate costs) */ \
-#define SNAPHASH_DF_EVAL(k, ex, cand, chk)                                                                      \
-        {                                                                                                       \
-            const bool vis_ = (ex) & (left != 0u);                                                              \
-            left -= vis_ ? 1u : 0u;                                                                             \
-            if (vis_ & (nochk | (chk == mine))) {                                                               \
-                const uint32_t l = extend_match(L, p, cand, maxl);                                              \
-                if (l > best) { /* (a branch: most extensions end short of the best, and the update is a dozen instructions) */ \
-                    best = l;                                                                                   \
-                    bdist = p - cand;                                                                           \
-                    left = (l >= kDfNice || l >= maxl) ? 0u : ((l >= kDfGood && left > depth / 4u) ? depth / 4u : left); \
-                }                                                                                               \
-            }                                                                                                   \
-        }
-        SNAPHASH_DF_EVAL(0u, e0, a0, k0) SNAPHASH_DF_EVAL(1u, e1, a1, k1) SNAPHASH_DF_EVAL(2u, e2, a2, k2) SNAPHASH_DF_EVAL(3u, e3, a3, k3)
+        SNAPHASH_DF_EVAL(0u, x0, v0, a0, k0) SNAPHASH_DF_EVAL(1u, x1, v1, a1, k1) SNAPHASH_DF_EVAL(2u, x2, v2, a2, k2) SNAPHASH_DF_EVAL(3u, x3, v3, a3, k3)
 #undef SNAPHASH_DF_EVAL
-        // on iff the chain goes on behind this batch (its last link exists) and budget is left
-        open = last_exists && left != 0u;
+        left = lim - (v3 ? 4u : (v2 ? 3u : (v1 ? 2u : (v0 ? 1u : 0u)))); // (`visited` of candidate k implies it of the ones before)
+        // on iff the chain goes on behind this batch (its last link is alive) and budget is left
+        open = !x3 && left != 0u;
         a0 = n0; a1 = n1; a2 = n2; a3 = n3;
-        e0 = f0; e1 = f1; e2 = f2; e3 = f3;
-        last_exists = f3;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        last_dead = y3;
     }
+#undef SNAPHASH_DF_LINK
+#undef SNAPHASH_DF_UPDATE
 #elif !defined(SNAPHASH_DF_BRANCHY_WALK) // round 5's walk before the pipeline (make unpipelined, for A/B): check, extend, update written out per candidate
     // (The inner decisions are selects, not branches: every `if` of a divergent wave costs scalar instructions for the
     // exec mask -- the kernel issued as many of those as vector instructions -- and only the ones that skip real work

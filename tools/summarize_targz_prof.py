@@ -21,7 +21,7 @@ ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(out, tag + "_kernel_stats.csv"))
 res = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_valu"):
     for f in glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):

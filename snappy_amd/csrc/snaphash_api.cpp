@@ -963,23 +963,35 @@ int gather_digest_slabs(snaphash_ctx* x, const std::vector<size_t>& cnt, size_t 
 
 // ---- planning (planner.h): which streams the kernels take and which the library's own host SHA-512 ------
 
-// bytes per second of the library's host SHA-512 on one core of THIS box (hosts differ 3x): timed once, on a
-// 512 KiB buffer, when a ctx that may plan is created (~1 ms)
+// bytes per second of the library's host SHA-512 on one core of THIS box (hosts differ 3x): timed on a 512 KiB buffer when a
+// ctx that may plan is created (~2 ms), the MEDIAN of five -- and smoothed over the ctxs of the process (the first stands, later
+// ones move it a quarter of the way): one bench run's ctxs measured 1.22 .. 1.94 GB/s on one box (a core still clocking up,
+// a sibling thread busy, the buffer hot in L2), config 5's 255 MiB head was planned at 218 ms where it takes 190, and a
+// 3 MiB file at 1.6 ms where it takes 2.4.  observe_host corrects the model only over calls of 5 ms and more.
 double measure_host_rate()
 {
+    static std::mutex mu;
+    static double smoothed = 0; // process-wide
     std::vector<uint8_t> buf(512u << 10, 0x5a);
     HostSha hs;
     uint8_t out[64];
-    double best = 0;
-    for (int rep = 0; rep < 3; ++rep) {
+    double rate[5];
+    int n = 0;
+    for (int rep = 0; rep < 5; ++rep) {
         host_sha512_init(hs);
         const double t0 = now_ms();
         host_sha512_update(hs, buf.data(), buf.size());
         host_sha512_final(hs, out);
         const double dt = (now_ms() - t0) * 1e-3;
-        if (dt > 0) best = std::max(best, (double)buf.size() / dt);
+        if (dt > 0) rate[n++] = (double)buf.size() / dt;
     }
-    return best > 50e6 ? best : 0.40e9;
+    if (n == 0) return 0.40e9;
+    std::sort(rate, rate + n);
+    const double median = rate[n / 2];
+    if (!(median > 50e6)) return 0.40e9;
+    std::lock_guard<std::mutex> lk(mu);
+    smoothed = smoothed > 0 ? 0.75 * smoothed + 0.25 * median : median;
+    return smoothed;
 }
 
 // descriptors this process holds right now (the entries of /proc/self/fd, less the one the listing itself uses); 0 = unknown

@@ -39,6 +39,7 @@
 #include "hostfill.h"
 #include "hostpass.h"
 #include "hostsha.h"
+#include "member_hashers.h"
 #include "planner.h"
 #include "sha512_core.h"
 #include "sha512_kernels.h"

@@ -2,7 +2,8 @@
 // available on the pool).  What runs on more than one thread beside the kernels: the level-wise parallel walk
 // (walk.cpp), the ranged YAML emitter and parser (hostpass.cpp), the persistent pool of staging-fill threads (hostfill.cpp
 // FillPool), the read-ahead reader of one long host-hashed file (hostsha.cpp) and the thread sets of a planned host
-// part (ThreadJoiner).  Exit code 0 = no report, every result equal to the single-threaded one.
+// part (ThreadJoiner), and -- round 5 -- the host threads that hash the fused Build pass's long members out of the staging
+// slots (member_hashers.h).  Exit code 0 = no report, every result equal to the single-threaded one.
 //
 // usage: tsan_host BUILD_DIR BIG_FILE
 #include <stdio.h>
@@ -18,6 +19,7 @@
 #include "../snappy_amd/csrc/hostfill.h"
 #include "../snappy_amd/csrc/hostpass.h"
 #include "../snappy_amd/csrc/hostsha.h"
+#include "../snappy_amd/csrc/member_hashers.h"
 
 using namespace snaphash;
 
@@ -154,6 +156,57 @@ int main(int argc, char** argv)
         const std::function<void(size_t)> fine = [&](size_t) { ok.fetch_add(1, std::memory_order_relaxed); };
         pool.parallel_for(3000, 4, fine);
         if (ok.load() != 3000) return 22;
+    }
+    // 6. round 5: the fused Build pass's long members on host threads (member_hashers.h).  A "packer" refills two slot buffers
+    //    in turn with the next stretch of a stream of members -- waiting for the workers that still read the buffer it is about
+    //    to overwrite -- and hands every member's piece to ITS worker; a member's digest must be the single-shot one.
+    {
+        const size_t kSlot = 192 << 10;
+        std::vector<uint64_t> sizes = {700001, 5, 200000, 1 << 20, 131072, 399999, 64, 250000, 1, 0x60000};
+        std::vector<std::vector<uint8_t>> data(sizes.size());
+        std::vector<uint8_t> want(sizes.size() * 64);
+        uint32_t seed = 99;
+        for (size_t k = 0; k < sizes.size(); ++k) {
+            data[k].resize(sizes[k]);
+            for (auto& b : data[k]) { seed = seed * 1664525u + 1013904223u; b = (uint8_t)(seed >> 24); }
+            HostSha hs;
+            host_sha512_init(hs);
+            host_sha512_update(hs, data[k].data(), data[k].size());
+            host_sha512_final(hs, want.data() + 64 * k);
+        }
+        for (unsigned workers : {1u, 3u, 16u}) {
+            MemberHashers mh;
+            mh.start(sizes, workers);
+            std::vector<uint8_t> slot[2] = {std::vector<uint8_t>(kSlot), std::vector<uint8_t>(kSlot)};
+            size_t member = 0;
+            uint64_t off = 0; // within the member
+            for (unsigned round = 0; member < sizes.size(); ++round) {
+                const int b = (int)(round & 1u);
+                mh.wait_slot(b);
+                size_t at = 0;
+                std::vector<MemberHashers::Task> tasks;
+                while (member < sizes.size() && at < kSlot) {
+                    const uint64_t take = std::min<uint64_t>(kSlot - at, sizes[member] - off);
+                    memcpy(slot[b].data() + at, data[member].data() + off, take);
+                    tasks.push_back(MemberHashers::Task{(uint32_t)member, slot[b].data() + at, take, off == 0, off + take == sizes[member], b});
+                    at += take;
+                    off += take;
+                    if (off == sizes[member]) { ++member; off = 0; }
+                }
+                for (const auto& t : tasks) mh.give(t);
+            }
+            mh.wait_all();
+            mh.stop();
+            if (mh.digests.size() != want.size() || memcmp(mh.digests.data(), want.data(), want.size()) != 0) return 23;
+            uint64_t total = 0;
+            for (uint64_t z : sizes) total += z;
+            if (mh.bytes != total) return 24;
+        }
+        { // stopped with work still queued (a pass that failed half-way): what is queued is done, nothing hangs
+            MemberHashers mh;
+            mh.start(sizes, 2);
+            for (size_t k = 0; k < sizes.size(); ++k) mh.give(MemberHashers::Task{(uint32_t)k, data[k].data(), sizes[k], true, true, (int)(k & 1)});
+        }
     }
     printf("tsan driver ok\n");
     return 0;

@@ -250,7 +250,11 @@ void snaphash_free(void *p);
  * stays in HBM between launches.  Streams are numbered 0 .. n_streams-1 by the caller.
  * finish pads and hashes what is left and writes n_streams digests (a stream that was never
  * appended to hashes as the empty file; a stream not ended is ended).  On a ctx with several devices the batch
- * runs on the first engine (a producer that feeds one chunk at a time is one PCIe link's worth of work at most). */
+ * runs on the first engine (a producer that feeds one chunk at a time is one PCIe link's worth of work at most).
+ * Every byte of a batch goes through the kernels, where ONE stream advances at ~44 MB/s (the chain is serial): a batch
+ * is for many streams of similar length.  A producer with long members among short ones hashes those itself, or hands
+ * the whole pass to snaphash_tar_create, which sends a member whose chain would outlast the pass to a host thread
+ * (reading it out of the staging buffer: still one read of every file). */
 typedef struct snaphash_batch snaphash_batch;
 int snaphash_batch_begin(snaphash_ctx *ctx, size_t n_streams, snaphash_batch **out);
 int snaphash_batch_append(snaphash_batch *b, size_t stream, const void *data, size_t n);
@@ -282,7 +286,10 @@ typedef struct snaphash_targz_stats { /* of the most recent snaphash_tar_create 
  * yaml_out != NULL fuses writeHashes into the same pass (row f2: every file is read ONCE): the SHA-512
  * kernels hash each regular file out of the staged tar stream, the archive digest is taken over the
  * bytes written, and *yaml_out receives hashes.yaml (snaphash_free); exclude_prefix must then be
- * writeHashes' own rule.  archive_digest (may be NULL): the 64 raw bytes of SHA-512(tarname).
+ * writeHashes' own rule.  A LONG member -- one whose SHA-512 chain would outlast its share of the pass on the GPU, where a
+ * lone stream advances at ~44 MB/s -- is hashed by a host thread instead, out of the staging buffer the packer has read it
+ * into (still one read; SNAPHASH_FLAG_GPU_ONLY keeps every byte on the kernels).
+ * archive_digest (may be NULL): the 64 raw bytes of SHA-512(tarname).
  * tarname is created as os.Create does (deb.go:264) with one difference in timing: a file already there is
  * overwritten from offset 0 and cut to the new length when the last byte is written, not emptied first (emptying a
  * previous 250 MiB archive stalled the whole pipeline for 25-30 ms); it is unlinked when the pass fails.

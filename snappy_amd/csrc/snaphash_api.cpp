@@ -2620,13 +2620,42 @@ int files_equal_impl(DevCtx* c, const char* const* a, const char* const* b, size
     }
     c->stats.streams = n;
     if (todo.empty()) return SNAPHASH_OK;
-    int rc = ensure_slots(c);
+    uint64_t total = 0;
+    for (const CmpPair& p : todo) total += p.len;
+    // Small comparisons stay on the host (round 5; the planner's rule for the hash pass -- never slower than the loop it
+    // replaces -- applied here): helpers.FilesAreEqual compares 4 KiB chunks on one goroutine (cmp.go:57-77), and what
+    // policy.AppArmorDelta hands it is a handful of profile files of a few KiB.  Through the staging buffers that was two
+    // pinned allocations (80 ms on a fresh ctx), two copies and a launch for microseconds of memcmp.  Up to 16 MiB a side
+    // the pairs are read and compared by the helper threads; SNAPHASH_FLAG_GPU_ONLY keeps every byte on the kernel.
+    if (!(c->owner && c->owner->gpu_only) && total <= (uint64_t)(16u << 20)) {
+        const unsigned T = (unsigned)std::min<size_t>(std::max<size_t>(1, std::min<uint64_t>(todo.size(), total >> 16)), 8);
+        std::atomic<size_t> next_pair{0};
+        run_on_threads(T, [&](unsigned) {
+            std::vector<uint8_t> ba(64u << 10), bb(64u << 10);
+            for (size_t t; (t = next_pair.fetch_add(1)) < todo.size();) {
+                const CmpPair& p = todo[t];
+                bool same = true;
+                for (uint64_t off = 0; off < p.len && same; off += ba.size()) {
+                    const uint64_t take = std::min<uint64_t>(ba.size(), p.len - off);
+                    same = read_exact(a[p.idx], off, take, ba.data()) && read_exact(b[p.idx], off, take, bb.data()) && memcmp(ba.data(), bb.data(), take) == 0;
+                }
+                equal[p.idx] = same ? 1 : 0;
+            }
+        });
+        return SNAPHASH_OK;
+    }
+    // (the staging halves sized for the job: pinning 2 x 256 MiB for a few MiB of files cost more than comparing them)
+    uint64_t slot_want = 8u << 20;
+    while (slot_want < c->staging && slot_want < 2 * total) slot_want <<= 1;
+    slot_want = std::min<uint64_t>(slot_want, c->staging);
+    for (const Slot& sl : c->slot) slot_want = std::max<uint64_t>(slot_want, std::min<uint64_t>(sl.cap, c->staging));
+    int rc = ensure_slots(c, 2, slot_want);
     if (rc) return rc;
     for (const CmpPair& p : todo) equal[p.idx] = 1; // AND-ed down batch by batch
     // Two halves of the staging buffers (A side: slot 0, B side: slot 1) alternate: the files of batch k+1
     // are read and copied while the compare kernel of batch k runs; a batch's verdicts are collected when
     // its half is needed again.
-    const uint64_t H = (c->staging / 2) & ~(uint64_t)(kAlign - 1);
+    const uint64_t H = (slot_want / 2) & ~(uint64_t)(kAlign - 1);
     struct Seg { size_t t; uint64_t at, off, n; };
     struct Half {
         std::vector<Seg> segs;

@@ -156,3 +156,30 @@ def test_gpu_ranges_equal_device(ctx):
     ctx.ranges_equal_device(a.data_ptr(), off, b.data_ptr(), off, lens, out.data_ptr())
     ctx.sync()
     assert out.cpu().numpy().tolist() == [1, 1, 1, 0, 1, 1, 1, 0, 1, 0]
+
+
+@pytest.mark.gpu
+def test_small_comparisons_stay_on_the_host_by_default(built_lib, oracle, tmp_path, snaphash_mode):
+    """Round 5 (tools/cmp_small_probe.py): what policy.AppArmorDelta hands DirUpdated is a few dozen profile files of a few
+    KiB (policy/policy.go:162 -> helpers/cmp.go:81-114).  In the default configuration such a job is read and compared by host
+    threads -- no staging buffer is pinned for it -- and with SNAPHASH_FLAG_GPU_ONLY it goes through the compare kernel with
+    staging halves sized for the job; the verdicts are the oracle's either way."""
+    from snappy_amd import Context
+    rng = np.random.default_rng(8)
+    pairs = []
+    for i in range(40):
+        data = rng.integers(0, 256, size=int(rng.integers(1, 9000)), dtype=np.uint8).tobytes()
+        a, b = str(tmp_path / ("p%d" % i)), str(tmp_path / ("q%d" % i))
+        _w(a, data)
+        _w(b, data if i % 5 else data[:-1] + bytes([data[-1] ^ 1]))
+        pairs.append((a, b))
+    pairs.append((pairs[0][0], str(tmp_path / "missing")))
+    want = [oracle.files_equal(a, b) for a, b in pairs]
+    assert any(want) and not all(want)
+    with Context() as c:
+        assert c.files_equal(pairs) == want
+        pinned = c.engine_info(0)["pinned_bytes"]
+        if snaphash_mode == "gpu_only":
+            assert 0 < pinned <= 24 << 20, pinned  # two 8 MiB slots and the verdict buffers, not two of 256 MiB
+        else:
+            assert pinned <= 8 << 20, pinned  # (what the link probe of a planning ctx left behind at init, nothing more)

@@ -389,3 +389,42 @@ def test_gpu_deflate_equals_model_on_random_structures(built_lib, f3):  # noqa: 
             model = ctypes.string_at(p, n.value)
             f3.f3_free(p)
             assert gz == model, (it, len(data))
+
+
+@pytest.mark.gpu
+def test_long_members_of_a_package_go_to_host_threads_and_the_buffers_fit_the_job(built_lib, oracle, tmp_path, snaphash_mode):
+    """Round 5 (tools/build_small_probe.py): a package as most snaps are -- many small files, a few long ones.  A lone SHA-512
+    chain is 44 MB/s on the GPU, so in the default configuration a member whose chain would outlast its share of the pass is
+    hashed by a host thread out of the pinned staging buffer (still one read of every file); SNAPHASH_FLAG_GPU_ONLY keeps
+    every byte on the kernels.  hashes.yaml is the oracle's either way, the archive inflates to the tree -- and the staging
+    and output buffers are sized for the 9 MiB job, not the engine's 256 MiB staging size (a gigabyte of pinned memory)."""
+    from snappy_amd import Context
+    rng = np.random.default_rng(31)
+    sizes = [int(x) for x in rng.integers(0, 40000, size=150)] + [6 << 20, (3 << 19) + 5, 0, 129]
+    build, _ = trees.make_synthetic_tree(str(tmp_path), sizes + [1])
+    os.makedirs(os.path.join(build, "DEBIAN"))
+    open(os.path.join(build, "DEBIAN", "control"), "w").write("Package: x\n")
+    out = str(tmp_path / "data.tar.gz")
+    with Context() as c:
+        for _ in range(2):  # (the second pass reuses the buffers the first one made)
+            yaml_fused, digest = c.tar_create(out, build, build + "/DEBIAN", with_hashes=True)
+            ex = c.stats_ex()
+            if snaphash_mode == "gpu_only":
+                assert ex["host_streams"] == 1 and ex["host_bytes"] == os.path.getsize(out)
+            else:  # the archive and the two long members
+                assert ex["host_streams"] == 3 and ex["host_bytes"] == os.path.getsize(out) + (6 << 20) + (3 << 19) + 5
+            assert oracle.hashes_yaml(build, out) == yaml_fused
+            assert hashlib.sha512(open(out, "rb").read()).digest() == digest
+        info = c.engine_info(0)
+        assert 0 < info["pinned_bytes"] <= 96 << 20, info  # two 16 MiB slots, two output buffers of their size, small tables
+    with tarfile.open(out, "r:gz") as tf:
+        names = [m.name for m in tf if m.isreg()]
+        assert len(names) == len(sizes)
+    # one file of 1 MiB: 24 ms of one chain on the GPU, ~1 ms on a core
+    one = str(tmp_path / "one")
+    os.makedirs(os.path.join(one, "DEBIAN"))
+    open(os.path.join(one, "payload.bin"), "wb").write(rng.integers(0, 256, size=1 << 20, dtype=np.uint8).tobytes())
+    with Context() as c:
+        y, _ = c.tar_create(out, one, one + "/DEBIAN", with_hashes=True)
+        assert oracle.hashes_yaml(one, out) == y
+        assert c.stats_ex()["host_streams"] == (1 if snaphash_mode == "gpu_only" else 2)

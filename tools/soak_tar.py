@@ -2,7 +2,9 @@
 """Soak of the data.tar.gz producer at its default staging size: random trees of 70-400 MiB (a few big members that straddle
 the 64 MiB parts of the first slot and the 256 MiB slots, many small ones, empty files, long names), every pass checked:
 the archive inflates to the tar stream the host model lays out, archive digest = hashlib, hashes.yaml = the oracle's.
-usage: tools/soak_tar.py [seconds=240] [seed=1]"""
+usage: tools/soak_tar.py [seconds=240] [seed=1] [mixed]
+"mixed" (round 5): small packages (0.05-40 MiB, what most snaps are) between the large ones, in ONE ctx: the producer's buffers are
+sized for the job and grow when a later one needs more, and long members are hashed by host threads out of the staging slots."""
 import ctypes, gzip, hashlib, os, shutil, subprocess, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +14,7 @@ from oracle import oracle  # noqa: E402  (the checker)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+mixed = len(sys.argv) > 3 and sys.argv[3] == "mixed"
 tmp = tempfile.mkdtemp(prefix="snaphash_soaktar_", dir="/dev/shm")
 sodir = tempfile.mkdtemp(prefix="snaphash_soaktar_so_")  # (/dev/shm is mounted noexec on the GPU box)
 so = os.path.join(sodir, "libf3host.so")
@@ -30,11 +33,15 @@ try:
             build = os.path.join(tmp, "t%d" % it)
             os.makedirs(os.path.join(build, "DEBIAN"))
             open(os.path.join(build, "DEBIAN", "control"), "w").write("Package: soak\n")
-            want = int(rng.integers(70, 400)) * MiB
+            small = mixed and rng.random() < 0.7
+            want = int(rng.integers(50 << 10, 40 * MiB)) if small else int(rng.integers(70, 400)) * MiB
             have, k = 0, 0
             while have < want:
                 kind = rng.random()
-                size = int(rng.integers(20, 130) * MiB + rng.integers(0, 4096)) if kind < 0.15 else int(rng.choice([0, 1, 511, 512, 513, 65535, 65536])) if kind < 0.3 else int(rng.integers(0, 3 * MiB))
+                if small:
+                    size = int(rng.integers(1, 12) * MiB + rng.integers(0, 4096)) if kind < 0.05 else int(rng.choice([0, 1, 511, 512, 513, 65535, 65536])) if kind < 0.3 else int(rng.lognormal(np.log(20000), 1.5))
+                else:
+                    size = int(rng.integers(20, 130) * MiB + rng.integers(0, 4096)) if kind < 0.15 else int(rng.choice([0, 1, 511, 512, 513, 65535, 65536])) if kind < 0.3 else int(rng.integers(0, 3 * MiB))
                 src = text if rng.random() < 0.5 else pool
                 off = int(rng.integers(0, max(1, len(src) - min(size, len(src)))))
                 d = os.path.join(build, "d%d" % int(rng.integers(0, 5)))
@@ -64,8 +71,8 @@ try:
             shutil.rmtree(build)
             if it % 5 == 0:
                 print("  ... %d trees, %.1f GiB of tar stream so far" % (it, total / 2**30), flush=True)
-    print("soak_tar: %d trees, %.1f GiB of tar stream (70-400 MiB each, default staging: first slot in 64 MiB parts), every archive inflates to its tar stream, "
-          "digest = hashlib, hashes.yaml = the oracle's" % (it, total / 2**30))
+    print("soak_tar: %d trees, %.1f GiB of tar stream (%s, default staging: first slot in 64 MiB parts), every archive inflates to its tar stream, "
+          "digest = hashlib, hashes.yaml = the oracle's" % (it, total / 2**30, "0.05-40 MiB and 70-400 MiB mixed in one ctx" if mixed else "70-400 MiB each"))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
     shutil.rmtree(sodir, ignore_errors=True)

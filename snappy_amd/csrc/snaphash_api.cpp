@@ -2633,13 +2633,26 @@ int files_equal_impl(DevCtx* c, const char* const* a, const char* const* b, size
         std::atomic<size_t> next_pair{0};
         run_on_threads(T, [&](unsigned) {
             std::vector<uint8_t> ba(64u << 10), bb(64u << 10);
+            auto pread_all = [](int fd, uint8_t* dst, uint64_t n, uint64_t off) {
+                uint64_t got = 0;
+                while (got < n) {
+                    const ssize_t r = pread(fd, dst + got, n - got, (off_t)(off + got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) return false; // an error, or a file that shrank since its size was taken: not equal (cmp.go:31-56)
+                    got += (uint64_t)r;
+                }
+                return true;
+            };
             for (size_t t; (t = next_pair.fetch_add(1)) < todo.size();) {
                 const CmpPair& p = todo[t];
-                bool same = true;
+                const int fa = open(a[p.idx], O_RDONLY | O_CLOEXEC), fb = fa >= 0 ? open(b[p.idx], O_RDONLY | O_CLOEXEC) : -1;
+                bool same = fa >= 0 && fb >= 0;
                 for (uint64_t off = 0; off < p.len && same; off += ba.size()) {
                     const uint64_t take = std::min<uint64_t>(ba.size(), p.len - off);
-                    same = read_exact(a[p.idx], off, take, ba.data()) && read_exact(b[p.idx], off, take, bb.data()) && memcmp(ba.data(), bb.data(), take) == 0;
+                    same = pread_all(fa, ba.data(), take, off) && pread_all(fb, bb.data(), take, off) && memcmp(ba.data(), bb.data(), take) == 0;
                 }
+                if (fa >= 0) close(fa);
+                if (fb >= 0) close(fb);
                 equal[p.idx] = same ? 1 : 0;
             }
         });

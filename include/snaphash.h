@@ -99,11 +99,12 @@ typedef struct snaphash_config {
     uint64_t staging_bytes; /* size of EACH of the two pinned-host/HBM staging buffers per device; 0 = 256 MiB */
     uint32_t kernel;        /* SNAPHASH_KERNEL_* */
     uint32_t deflate_depth; /* (ABI 4; was reserved, must be 0 before) the data.tar.gz producer's effort: hash-chain links the
-                               DEFLATE search walks per position.  0 = 72 (since round 5; 32 before): the bytes of the
-                               reference's gzip level 9 (clickdeb/deb.go:271) within half a percent -- text 0.2404 of the
-                               input against zlib -9's 0.2394-0.2397 -- and as fast as the one stream that bounds the fused pass
-                               anyway (the archive's SHA-512 on a host core).  32 = about zlib level 6's output at 0.82x the
-                               kernel time, 96 = zlib -9's bytes and under at 1.1x.  4 .. 256, rounded down to a multiple of 4. */
+                               DEFLATE search walks per position.  0 = 96 (since round 5; 32 before): the bytes of the
+                               reference's gzip level 9 (clickdeb/deb.go:271) -- text 0.2392-0.2397 of the input against
+                               zlib -9's 0.2394-0.2397, sources within 0.1 %, binaries under -- and still ahead of the one stream
+                               that bounds the fused pass (the archive's SHA-512 on a host core).  32 = about zlib level 6's
+                               output at 0.74x the kernel time, 72 = zlib -9's + 0.5 % at 0.9x.  4 .. 256, rounded down to a
+                               multiple of 4. */
     void *stream;           /* hipStream_t to launch on (single-device ctx only); NULL = a stream owned by the ctx */
     /* ---- ABI 2 ---- */
     const int32_t *devices; /* n_devices HIP ordinals: the GPUs of the node this ctx shards over.  A single

@@ -34,7 +34,7 @@ static int usage(void)
                     "       verify DIR YAML [TAR] | build DIR OUT.tar.gz | gzip IN OUT.gz | cmp A B [A B ...] |\n"
                     "       dirupdated DIR_A DIR_B [PREFIX] | plan FILE... (what the planner would do; no device needed)\n"
                     "       -g: every byte through the HIP kernels (SNAPHASH_FLAG_GPU_ONLY); default: every call is planned\n"
-                    "       -z DEPTH: effort of `build` / `gzip` (hash-chain links per position; default 72 = gzip -9's class, 32 = gzip -6's)\n");
+                    "       -z DEPTH: effort of `build` / `gzip` (hash-chain links per position; default 96 = gzip -9's bytes, 32 = gzip -6's)\n");
     return 2;
 }
 

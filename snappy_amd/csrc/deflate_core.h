@@ -99,7 +99,7 @@ constexpr uint32_t kDfMaxDist = 28800;  // farthest match; also the bytes in fro
 constexpr uint32_t kDfMinMatch = 3;
 constexpr uint32_t kDfTooFar = 4096;    // a 3-byte match farther than this costs more than its literals (zlib's TOO_FAR)
 #if !defined(SNAPHASH_DF_DEPTH) // (tuning builds override the two search parameters; the CPU model follows)
-#define SNAPHASH_DF_DEPTH 72 // (round 5: 32 before; the bytes of the reference's gzip level 9 -- text 0.2404 against zlib -9's 0.2394-0.2397 -- at what depth 32 cost before the search was counted out instruction by instruction: DESIGN.md sec. 9)
+#define SNAPHASH_DF_DEPTH 96 // (round 5: 32 before; the bytes of the reference's gzip level 9 -- text 0.2392-0.2397 against zlib -9's 0.2394-0.2397 -- for 1.1 x what depth 32 cost before the search was counted out instruction by instruction, inside a fused pass that got faster: DESIGN.md sec. 9)
 #define SNAPHASH_DF_GOOD 32
 #endif
 constexpr uint32_t kDfDepth = SNAPHASH_DF_DEPTH; // links walked per position

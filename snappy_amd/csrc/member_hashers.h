@@ -93,6 +93,15 @@ struct MemberHashers {
         { std::lock_guard<std::mutex> lk(mu); ++outstanding[t.slot]; workers[worker_of[t.h]]->q.push_back(t); }
         cv_work.notify_all();
     }
+    void give_all(const std::vector<Task>& ts) // a slot's worth at once: one lock, one wake-up
+    {
+        if (ts.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (const Task& t : ts) { ++outstanding[t.slot]; workers[worker_of[t.h]]->q.push_back(t); }
+        }
+        cv_work.notify_all();
+    }
     void wait_slot(int slot) // before the slot's host buffer is written again
     {
         std::unique_lock<std::mutex> lk(mu);

@@ -47,7 +47,7 @@ def test_gpu_deflate_round_trips_and_equals_its_cpu_model(built_lib, f3):  # noq
 @pytest.mark.kernels_only("the DEFLATE kernel alone: nothing in it is planned")
 def test_deflate_depth_is_the_models_depth(built_lib, f3):  # noqa: F811
     """snaphash_config.deflate_depth (ABI 4): the producer's effort -- hash-chain links walked per position.  At 8, 32, the
-    default (0 = 72 since round 5: the class of the reference's gzip level 9, clickdeb/deb.go:271) and 128 the GPU's bytes
+    default (0 = 96 since round 5: the class of the reference's gzip level 9, clickdeb/deb.go:271) and 128 the GPU's bytes
     equal the serial model's at that depth, gzip reads them back, and a deeper walk never writes more on compressible input."""
     import ctypes
     from snappy_amd import Context
@@ -66,9 +66,9 @@ def test_deflate_depth_is_the_models_depth(built_lib, f3):  # noqa: F811
                 model = ctypes.string_at(p, n.value)
                 f3.f3_free(p)
                 assert gz == model, (name, depth)
-                sizes[(name, depth or 72)] = len(gz)
+                sizes[(name, depth or 96)] = len(gz)
     for name in ("text", "sources"):
-        assert sizes[(name, 8)] > sizes[(name, 32)] > sizes[(name, 72)] >= sizes[(name, 128)], sizes
+        assert sizes[(name, 8)] > sizes[(name, 32)] > sizes[(name, 96)] >= sizes[(name, 128)], sizes
 
 
 def test_tar_create_matches_tarfile_view_of_the_tree(built_lib, tmp_path):
@@ -394,11 +394,13 @@ def test_gpu_deflate_equals_model_on_random_structures(built_lib, f3):  # noqa: 
 @pytest.mark.gpu
 def test_long_members_of_a_package_go_to_host_threads_and_the_buffers_fit_the_job(built_lib, oracle, tmp_path, snaphash_mode):
     """Round 5 (tools/build_small_probe.py): a package as most snaps are -- many small files, a few long ones.  A lone SHA-512
-    chain is 44 MB/s on the GPU, so in the default configuration a member whose chain would outlast its share of the pass is
-    hashed by a host thread out of the pinned staging buffer (still one read of every file); SNAPHASH_FLAG_GPU_ONLY keeps
-    every byte on the kernels.  hashes.yaml is the oracle's either way, the archive inflates to the tree -- and the staging
-    and output buffers are sized for the 9 MiB job, not the engine's 256 MiB staging size (a gigabyte of pinned memory)."""
-    from snappy_amd import Context
+    chain is 44 MB/s on the GPU, and a hashing workgroup beside the compressor costs it a fifth round of workgroups: in the
+    default configuration the members are hashed by host threads out of the pinned staging buffer (still one read of every
+    file) -- all of them with eight cores or more, the long ones with fewer; SNAPHASH_FLAG_GPU_ONLY keeps every byte on the
+    kernels.  hashes.yaml is the oracle's either way, the archive inflates to the tree -- and the staging and output buffers
+    are sized for the 9 MiB job, not the engine's 256 MiB staging size (a gigabyte of pinned memory)."""
+    from snappy_amd import Context, _lib
+    cores = int(_lib.lib().snaphash_usable_cpus())
     rng = np.random.default_rng(31)
     sizes = [int(x) for x in rng.integers(0, 40000, size=150)] + [6 << 20, (3 << 19) + 5, 0, 129]
     build, _ = trees.make_synthetic_tree(str(tmp_path), sizes + [1])
@@ -411,6 +413,8 @@ def test_long_members_of_a_package_go_to_host_threads_and_the_buffers_fit_the_jo
             ex = c.stats_ex()
             if snaphash_mode == "gpu_only":
                 assert ex["host_streams"] == 1 and ex["host_bytes"] == os.path.getsize(out)
+            elif cores >= 8:  # the archive and every member, the empty one included
+                assert ex["host_streams"] == 1 + len(sizes) and ex["host_bytes"] == os.path.getsize(out) + sum(sizes)
             else:  # the archive and the two long members
                 assert ex["host_streams"] == 3 and ex["host_bytes"] == os.path.getsize(out) + (6 << 20) + (3 << 19) + 5
             assert oracle.hashes_yaml(build, out) == yaml_fused

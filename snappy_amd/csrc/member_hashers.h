@@ -19,12 +19,12 @@ namespace snaphash {
 
 // Every member's SHA-512 used to go to the kernels, out of the staged tar stream -- and a lone SHA-512 chain advances
 // at 44 MB/s on the GPU: a package of 3 000 files with a 16 MiB binary among them took 460 ms where
-// its bytes pass in 80, a single 1 MiB file 24 ms (tools/build_small_probe.py; bench.py's tree is 1 MiB files, whose
-// 24 ms chains hide inside a 200 ms pass).  What `snaphash_tree` does through the planner the fused pass does here with
-// one rule: a member whose chain on the GPU would outlast the pass itself -- size / 44 MB/s > the pass's estimated time --
-// is hashed by a host thread instead (1.4 GB/s a core), FROM THE PINNED STAGING BUFFER the packer has just read it into:
-// every file is still read once.  A member's pieces (it may span slots) go to ONE worker in slot order; a slot's host
-// buffer is not refilled while a worker still reads it.  SNAPHASH_FLAG_GPU_ONLY: every byte through the kernels, as before.
+// its bytes pass in 80, a single 1 MiB file 24 ms (tools/build_small_probe.py); and a hashing workgroup beside the
+// compressor costs it a fifth round of workgroups (profiles/r05_deflate_depths.txt).  Which members come here is the
+// producer's decision (targz.inc: all of them with eight cores or more, the long ones with fewer, none under
+// SNAPHASH_FLAG_GPU_ONLY); this is the mechanism: a member's bytes are hashed FROM THE PINNED STAGING BUFFER the packer has
+// just read them into -- every file is still read once -- its pieces (it may span slots) go to ONE worker in slot order,
+// and a slot's host buffer is not refilled while a worker still reads it.
 struct MemberHashers {
     struct Task { uint32_t h; const uint8_t* p; uint64_t n; bool first, fin; int slot; };
     struct Worker { std::thread th; std::deque<Task> q; };
